@@ -1,0 +1,179 @@
+/*
+ * mvx.h — C ABI of the MI355X-native molecular voxelizer (libmvx_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of SeonghwanSeo/molvoxel:
+ * Voxelizer.forward_features / forward_types / forward_single (and the loop over a batch of
+ * molecules the reference's timing harness runs, test/test_time_numpy.py:11-15).
+ * The reference has no FFI layer of its own (it is pure Python); what it would bind is
+ * exactly this header, from a new backend module molvoxel/voxelizer/hip/voxelizer.py via
+ * ctypes (see INTEGRATION.md for the stub). Citations are file:line in the reference tree.
+ *
+ * Conventions
+ *   - every function returns 0 (MVX_OK) or a negative mvx_status; mvx_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - no ownership transfer: every buffer is caller-owned. Pointers are tagged host/device by
+ *     the *_kind arguments (MVX_HOST / MVX_DEVICE). Device pointers must belong to the handle's
+ *     device; `out` must be 16-byte aligned.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). With MVX_DEVICE
+ *     outputs the call is asynchronous on that stream; with MVX_HOST outputs it returns after
+ *     the copy back has completed.
+ *   - a handle is not re-entrant: use one handle per host thread / per stream.
+ *   - argument-shape errors are the Python layer's AssertionErrors (same messages as the
+ *     reference, molvoxel/voxelizer/numpy/voxelizer.py:181-192, 327-342, 443-455) and are
+ *     raised before the call; this library only validates what it needs to stay memory-safe.
+ *
+ * Numerical contract (verified against the imported reference by the goldens)
+ *   An atom n at p (fp64, after centring / transform) with radius r contributes to voxel
+ *   (i,j,k), g[i] = i*res - res*(D-1)/2, iff it passes
+ *     1. the box cull            molvoxel/voxelizer/numpy/voxelizer.py:481-494  (strict, fp64)
+ *     2. the cull of the reference block (blockdim) holding the voxel   :496-527 (strict, fp64)
+ *     3. float32( float32(sqrt_f64((dx^2+dy^2)+dz^2)) / float32(r) ) <= 1          :544-555
+ *   with value 1 (binary) or exp(-0.5*(dr/sigma)^2) in float32 (gaussian)            :557-560.
+ *   Membership (1-3) is reproduced exactly; gaussian values agree to ~1e-6.
+ */
+#ifndef MVX_H
+#define MVX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVX_VERSION 100 /* 0.1.0 */
+
+typedef enum mvx_status {
+    MVX_OK = 0,
+    MVX_ERR_INVALID = -1, /* bad argument */
+    MVX_ERR_HIP = -2,     /* a HIP runtime call failed (message has the hipError string) */
+    MVX_ERR_NO_DEVICE = -3,
+    MVX_ERR_ALLOC = -4
+} mvx_status;
+
+enum mvx_memkind { MVX_HOST = 0, MVX_DEVICE = 1 };
+enum mvx_density { MVX_GAUSSIAN = 0, MVX_BINARY = 1 }; /* base/voxelizer.py:13  DENSITY_TYPE_LIST */
+enum mvx_radii {                                         /* base/voxelizer.py:12  RADII_TYPE_LIST */
+    MVX_RADII_SCALAR = 0,  /* one python float for every atom */
+    MVX_RADII_ATOM = 1,    /* float32 (N,)   "atom-wise"    */
+    MVX_RADII_CHANNEL = 2  /* float32 (C,)   "channel-wise" */
+};
+enum mvx_xform_flags {
+    MVX_XF_CENTER = 1,    /* p = p - center first */
+    MVX_XF_ROTATE = 2,    /* p = q * p * q^-1 */
+    MVX_XF_TRANSLATE = 4, /* p = p + trans (twice when MVX_XF_ROTATE is also set, as the reference does) */
+    MVX_XF_RECENTER = 8   /* p = p + center after the rotation (do_transform with a center, numpy/transform.py:51-54) */
+};
+
+/*
+ * Geometry + density of one voxelizer. Replaces the constructor state of
+ * BaseVoxelizer.__init__ (base/voxelizer.py:15-38) and numpy Voxelizer.__init__/_setup_block
+ * (numpy/voxelizer.py:22-58).
+ */
+typedef struct mvx_config {
+    double resolution; /* base/voxelizer.py:26 */
+    double sigma;      /* base/voxelizer.py:37-38, default 0.5; ignored for binary */
+    int32_t dimension; /* D = H = W */
+    int32_t blockdim;  /* reference `blockdim` whose per-block cull is emulated (numpy/voxelizer.py:38,55);
+                          <= 0 means the reference default 8; >= dimension means one block (no block cull) */
+    int32_t density;   /* enum mvx_density */
+    int32_t device;    /* HIP device ordinal */
+} mvx_config;
+
+/*
+ * Per-molecule rigid transform applied on the device before voxelization, in exactly the
+ * reference's fp64 operation order: p = coords - center (numpy/voxelizer.py:120-121), then
+ * do_transform(p, None, translation, quaternion) (numpy/transform.py:44-60, _quaternion.py:24-50),
+ * including the reference's double application of the translation when a rotation is present.
+ */
+typedef struct mvx_xform {
+    double center[3];
+    double quat[4];   /* (q0, q1, q2, q3) as returned by random_quaternion, _quaternion.py:13-21 */
+    float trans[3];   /* float32 like numpy/transform.py:76 */
+    uint32_t flags;   /* enum mvx_xform_flags */
+} mvx_xform;
+
+typedef struct mvx_handle mvx_handle;
+
+int mvx_version(void);
+const char *mvx_last_error(void);
+int mvx_device_count(int *count);
+
+/* Replaces create_voxelizer(..., library=...) -> Voxelizer(...)  (molvoxel/__init__.py:25-40). */
+int mvx_create(const mvx_config *cfg, mvx_handle **out);
+int mvx_destroy(mvx_handle *h);
+/* Replaces the density_type property setter (base/voxelizer.py:65-70). */
+int mvx_set_density(mvx_handle *h, int32_t density, double sigma);
+
+/*
+ * Batched entry points: B molecules stored back to back, molecule b owning atoms
+ * [offsets[b], offsets[b+1]). `offsets` (B+1 int64) and `xforms` (B records, may be NULL =
+ * identity) are host pointers. coords / features / types / radii share `in_kind`.
+ * out is (B, C, D, D, D) float32, fully overwritten (zeros included), `out_kind` tagged.
+ *
+ *   radii_type SCALAR : radius = radius_scalar for every atom (radii ignored, may be NULL)
+ *              ATOM   : radii[sumN]
+ *              CHANNEL: radii[C], shared by all molecules. forward_types gathers radii[types]
+ *                       (numpy/voxelizer.py:284-285); forward_features tests each channel with its
+ *                       own radius and culls with max(radii) (numpy/voxelizer.py:138,213-224).
+ *
+ * mvx_forward_features_batch replaces Voxelizer.forward_features (numpy/voxelizer.py:97-169)
+ *   features: (sumN, C) float32 row-major.
+ * mvx_forward_types_batch replaces Voxelizer.forward_types (numpy/voxelizer.py:240-315)
+ *   types: (sumN,) int32 in [0, C); out has C channels (C may exceed max(types)+1, numpy/voxelizer.py:337).
+ * mvx_forward_single_batch replaces Voxelizer.forward_single (numpy/voxelizer.py:370-436)
+ *   out is (B, 1, D, D, D).
+ */
+int mvx_forward_features_batch(mvx_handle *h, const double *coords, const float *features, const float *radii,
+                               double radius_scalar, int32_t radii_type, const int64_t *offsets,
+                               const mvx_xform *xforms, int32_t B, int32_t C, float *out, int32_t in_kind,
+                               int32_t out_kind, void *stream);
+int mvx_forward_types_batch(mvx_handle *h, const double *coords, const int32_t *types, const float *radii,
+                            double radius_scalar, int32_t radii_type, const int64_t *offsets,
+                            const mvx_xform *xforms, int32_t B, int32_t C, float *out, int32_t in_kind,
+                            int32_t out_kind, void *stream);
+int mvx_forward_single_batch(mvx_handle *h, const double *coords, const float *radii, double radius_scalar,
+                             int32_t radii_type, const int64_t *offsets, const mvx_xform *xforms, int32_t B,
+                             float *out, int32_t in_kind, int32_t out_kind, void *stream);
+
+/* Single-molecule forms (B = 1, xform may be NULL): the reference's per-call signature. */
+int mvx_forward_features(mvx_handle *h, const double *coords, const float *features, const float *radii,
+                         double radius_scalar, int32_t radii_type, int64_t N, int32_t C, const mvx_xform *xform,
+                         float *out, int32_t in_kind, int32_t out_kind, void *stream);
+int mvx_forward_types(mvx_handle *h, const double *coords, const int32_t *types, const float *radii,
+                      double radius_scalar, int32_t radii_type, int64_t N, int32_t C, const mvx_xform *xform,
+                      float *out, int32_t in_kind, int32_t out_kind, void *stream);
+int mvx_forward_single(mvx_handle *h, const double *coords, const float *radii, double radius_scalar,
+                       int32_t radii_type, int64_t N, const mvx_xform *xform, float *out, int32_t in_kind,
+                       int32_t out_kind, void *stream);
+
+/*
+ * Replaces do_transform on an (N,3) fp64 point cloud (numpy/transform.py:44-60): out = transformed coords.
+ * Exposed so that RandomTransform/T objects can run on device-resident coordinates.
+ */
+int mvx_transform_coords(mvx_handle *h, const double *coords, int64_t N, const mvx_xform *xform, double *out,
+                         int32_t in_kind, int32_t out_kind, void *stream);
+
+/* Timing of the last voxelize launch on this handle, measured with HIP events on the launch
+ * stream around the dominant (voxelize) kernel only. Enabled by mvx_set_profiling(h, 1);
+ * mvx_last_kernel_ms synchronises on the stop event. Used by bench.py for `roofline.achieved`. */
+int mvx_set_profiling(mvx_handle *h, int32_t enable);
+int mvx_last_kernel_ms(mvx_handle *h, float *ms);
+
+/* Device memory helpers for callers without a device allocator of their own (torch-less use;
+ * numpy/voxelizer.py:60-70 get_empty_grid's role on the device). */
+int mvx_alloc(mvx_handle *h, int64_t bytes, void **ptr);
+int mvx_free(mvx_handle *h, void *ptr);
+int mvx_memcpy(mvx_handle *h, void *dst, const void *src, int64_t bytes, int32_t dst_kind, int32_t src_kind,
+               void *stream);
+int mvx_memset_zero(mvx_handle *h, void *ptr, int64_t bytes, void *stream);
+int mvx_stream_sync(mvx_handle *h, void *stream);
+
+/* Testing aid: copy the first n 64-byte atom records of the last call (px, py, pz, T as 4 doubles;
+ * k float; type int32; x/y/z admitted voxel ranges as lo | hi << 16; 12 B pad) to host memory.
+ * Synchronises the stream. Lets the tests check the prep stage (transform, culls, thresholds) alone. */
+int mvx_debug_read_records(mvx_handle *h, void *host_dst, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVX_H */

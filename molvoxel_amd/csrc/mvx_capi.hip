@@ -1,0 +1,589 @@
+// mvx_capi.hip — host side of libmvx_hip.so: the C ABI declared in include/mvx.h.
+//
+// Owns per-handle device workspace (atom records, ranges, metadata, staging for host-resident
+// arguments) and a small ring of pinned host slots so that calls with device-resident data are
+// fully asynchronous on the caller's stream (no hidden device synchronisation). There is no CPU
+// fallback in this library: without a usable HIP device mvx_create fails.
+#include "mvx_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace mvx;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return MVX_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) return fail_hip(_e, #expr); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct PinnedSlot {
+    char *p = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+};
+
+constexpr int NSLOTS = 4;
+
+} // namespace
+
+struct mvx_handle {
+    mvx_config cfg;
+    Geom g;
+    float sigma32;
+    int device;
+    DevBuf rec, bbox, meta, aux, in_coords, in_chan, in_radii, out_stage;
+    PinnedSlot slots[NSLOTS];
+    int next_slot = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profiling = false, timed = false;
+    int force_nw = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = (err == hipSuccess);
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+int ensure(DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return MVX_OK;
+    if (b.p) HIP_TRY(hipFree(b.p)); // synchronises: nothing in flight may still use the old buffer
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        g_err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return MVX_ERR_ALLOC;
+    }
+    b.cap = want;
+    return MVX_OK;
+}
+
+int acquire_slot(mvx_handle *h, size_t bytes, PinnedSlot **out) {
+    PinnedSlot &s = h->slots[h->next_slot];
+    h->next_slot = (h->next_slot + 1) % NSLOTS;
+    if (!s.done) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    if (s.in_flight) {
+        HIP_TRY(hipEventSynchronize(s.done));
+        s.in_flight = false;
+    }
+    if (bytes > s.cap) {
+        if (s.p) HIP_TRY(hipHostFree(s.p));
+        s.p = nullptr;
+        s.cap = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.p), want, hipHostMallocDefault));
+        s.cap = want;
+    }
+    *out = &s;
+    return MVX_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void make_geom(mvx_handle *h) {
+    const mvx_config &c = h->cfg;
+    Geom g;
+    g.res = c.resolution;
+    const double width = c.resolution * (double)(c.dimension - 1); // base/voxelizer.py:28
+    g.half = width / 2.0;                                          // base/voxelizer.py:33
+    g.D = c.dimension;
+    g.bd = c.blockdim > 0 ? c.blockdim : 8;                        // numpy/voxelizer.py:38
+    g.nb = (g.D + g.bd - 1) / g.bd;                                // numpy/voxelizer.py:44
+    h->g = g;
+    h->sigma32 = (float)c.sigma;
+}
+
+int pick_ct(int C) {
+    if (C <= 1) return 1;
+    if (C <= 4) return 4;
+    if (C <= 8) return 8;
+    if (C <= 16) return 16;
+    return 32;
+}
+
+struct RunArgs {
+    int mode;
+    const double *coords;
+    const void *channels; // float features (sumN, C) | int32 types (sumN) | null
+    const float *radii;
+    double radius_scalar;
+    int radii_type;
+    const int64_t *offsets;
+    const mvx_xform *xforms;
+    int B, C;
+    float *out;
+    int in_kind, out_kind;
+    hipStream_t stream;
+};
+
+int run(mvx_handle *h, const RunArgs &r) {
+    if (!h) return fail(MVX_ERR_INVALID, "null handle");
+    if (r.B < 0 || r.C <= 0) return fail(MVX_ERR_INVALID, "B must be >= 0 and C > 0");
+    if (r.B == 0) return MVX_OK;
+    if (!r.offsets || !r.out) return fail(MVX_ERR_INVALID, "offsets/out must not be null");
+    if (r.radii_type < MVX_RADII_SCALAR || r.radii_type > MVX_RADII_CHANNEL)
+        return fail(MVX_ERR_INVALID, "bad radii_type");
+    if (r.radii_type != MVX_RADII_SCALAR && !r.radii) return fail(MVX_ERR_INVALID, "radii array required");
+    if (r.radii_type == MVX_RADII_CHANNEL && r.mode == MODE_SINGLE)
+        return fail(MVX_ERR_INVALID, "Channel-Wise Radii Type is not supported"); // numpy/voxelizer.py:443
+    if ((r.in_kind != MVX_HOST && r.in_kind != MVX_DEVICE) || (r.out_kind != MVX_HOST && r.out_kind != MVX_DEVICE))
+        return fail(MVX_ERR_INVALID, "bad memory kind");
+    const int64_t total = r.offsets[r.B];
+    if (r.offsets[0] != 0) return fail(MVX_ERR_INVALID, "offsets[0] must be 0");
+    for (int b = 0; b < r.B; ++b)
+        if (r.offsets[b + 1] < r.offsets[b]) return fail(MVX_ERR_INVALID, "offsets must be non-decreasing");
+    if (total > 0 && !r.coords) return fail(MVX_ERR_INVALID, "coords must not be null");
+    if (total > 0 && r.mode != MODE_SINGLE && !r.channels) return fail(MVX_ERR_INVALID, "channels must not be null");
+    if (total >= (int64_t)1 << 31) return fail(MVX_ERR_INVALID, "too many atoms");
+
+    DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
+    hipStream_t s = r.stream;
+    const Geom &g = h->g;
+    const int D = g.D;
+    const size_t D3 = (size_t)D * D * D;
+    const size_t out_bytes = (size_t)r.B * r.C * D3 * sizeof(float);
+
+    // ---- host-side metadata (+ host-resident inputs) -> one pinned slot -> device ----------------
+    const size_t off_bytes = align_up((size_t)(r.B + 1) * sizeof(int64_t), 16);
+    const size_t xf_bytes = r.xforms ? align_up((size_t)r.B * sizeof(mvx_xform), 16) : 0;
+    const bool host_in = (r.in_kind == MVX_HOST);
+    const size_t chan_elem = (r.mode == MODE_FEATURES) ? (size_t)r.C * sizeof(float) : (r.mode == MODE_TYPES ? sizeof(int32_t) : 0);
+    const size_t co_bytes = host_in ? align_up((size_t)total * 3 * sizeof(double), 16) : 0;
+    const size_t ch_bytes = host_in ? align_up((size_t)total * chan_elem, 16) : 0;
+    size_t rad_count = 0;
+    if (r.radii_type == MVX_RADII_ATOM) rad_count = (size_t)total;
+    else if (r.radii_type == MVX_RADII_CHANNEL) rad_count = (size_t)r.C;
+    const size_t ra_bytes = host_in ? align_up(rad_count * sizeof(float), 16) : 0;
+
+    PinnedSlot *slot = nullptr;
+    int rc = acquire_slot(h, off_bytes + xf_bytes + co_bytes + ch_bytes + ra_bytes, &slot);
+    if (rc) return rc;
+    if ((rc = ensure(h->meta, off_bytes + xf_bytes))) return rc;
+    char *pin = slot->p;
+    std::memcpy(pin, r.offsets, (size_t)(r.B + 1) * sizeof(int64_t));
+    if (r.xforms) std::memcpy(pin + off_bytes, r.xforms, (size_t)r.B * sizeof(mvx_xform));
+    HIP_TRY(hipMemcpyAsync(h->meta.p, pin, off_bytes + xf_bytes, hipMemcpyHostToDevice, s));
+    const int64_t *d_off = reinterpret_cast<const int64_t *>(h->meta.p);
+    const mvx_xform *d_xf = r.xforms ? reinterpret_cast<const mvx_xform *>((char *)h->meta.p + off_bytes) : nullptr;
+
+    const double *d_coords = r.coords;
+    const void *d_chan = r.channels;
+    const float *d_radii = r.radii;
+    if (host_in && total > 0) {
+        char *q = pin + off_bytes + xf_bytes;
+        if ((rc = ensure(h->in_coords, co_bytes))) return rc;
+        std::memcpy(q, r.coords, (size_t)total * 3 * sizeof(double));
+        HIP_TRY(hipMemcpyAsync(h->in_coords.p, q, co_bytes, hipMemcpyHostToDevice, s));
+        d_coords = reinterpret_cast<const double *>(h->in_coords.p);
+        q += co_bytes;
+        if (ch_bytes) {
+            if ((rc = ensure(h->in_chan, ch_bytes))) return rc;
+            std::memcpy(q, r.channels, (size_t)total * chan_elem);
+            HIP_TRY(hipMemcpyAsync(h->in_chan.p, q, ch_bytes, hipMemcpyHostToDevice, s));
+            d_chan = h->in_chan.p;
+            q += ch_bytes;
+        }
+    }
+    if (host_in && rad_count > 0) {
+        char *q = pin + off_bytes + xf_bytes + co_bytes + ch_bytes;
+        if ((rc = ensure(h->in_radii, ra_bytes))) return rc;
+        std::memcpy(q, r.radii, rad_count * sizeof(float));
+        HIP_TRY(hipMemcpyAsync(h->in_radii.p, q, ra_bytes, hipMemcpyHostToDevice, s));
+        d_radii = reinterpret_cast<const float *>(h->in_radii.p);
+    }
+
+    float *d_out = r.out;
+    if (r.out_kind == MVX_HOST) {
+        if ((rc = ensure(h->out_stage, out_bytes))) return rc;
+        d_out = reinterpret_cast<float *>(h->out_stage.p);
+    } else if ((reinterpret_cast<uintptr_t>(r.out) & 15u) != 0) {
+        return fail(MVX_ERR_INVALID, "device out pointer must be 16-byte aligned");
+    }
+
+    // ---- workspace --------------------------------------------------------------------------------
+    const size_t n_alloc = (size_t)std::max<int64_t>(total, 1);
+    if ((rc = ensure(h->rec, n_alloc * sizeof(AtomRec)))) return rc;
+    if ((rc = ensure(h->bbox, n_alloc * sizeof(uint4)))) return rc;
+
+    const bool gauss = (h->cfg.density == MVX_GAUSSIAN);
+    const bool chanwise = (r.radii_type == MVX_RADII_CHANNEL && r.mode == MODE_FEATURES);
+    float *d_rmax = nullptr;
+    double *d_Tc = nullptr;
+    float *d_kc = nullptr;
+    if (chanwise) {
+        const size_t tc_off = 16, kc_off = tc_off + align_up((size_t)r.C * sizeof(double), 16);
+        if ((rc = ensure(h->aux, kc_off + (size_t)r.C * sizeof(float)))) return rc;
+        d_rmax = reinterpret_cast<float *>(h->aux.p);
+        d_Tc = reinterpret_cast<double *>((char *)h->aux.p + tc_off);
+        d_kc = reinterpret_cast<float *>((char *)h->aux.p + kc_off);
+        HIP_TRY(launch_chan_aux(d_radii, r.C, h->cfg.density, h->sigma32, d_rmax, d_Tc, d_kc, s));
+    }
+
+    // ---- prep -------------------------------------------------------------------------------------
+    PrepArgs pa;
+    pa.coords = d_coords;
+    pa.radii = d_radii;
+    pa.types = (r.mode == MODE_TYPES) ? reinterpret_cast<const int32_t *>(d_chan) : nullptr;
+    pa.offsets = d_off;
+    pa.xforms = d_xf;
+    pa.chan_aux = d_rmax;
+    pa.total = total;
+    pa.B = r.B;
+    pa.C = r.C;
+    pa.radius_scalar = r.radius_scalar;
+    if (r.radii_type == MVX_RADII_SCALAR) pa.radii_src = RAD_SCALAR;
+    else if (r.radii_type == MVX_RADII_ATOM) pa.radii_src = RAD_ATOM;
+    else pa.radii_src = chanwise ? RAD_CHANNEL_FEATURES : RAD_CHANNEL_BY_TYPE;
+    pa.density = h->cfg.density;
+    pa.sigma32 = h->sigma32;
+    pa.g = g;
+    pa.rec = reinterpret_cast<AtomRec *>(h->rec.p);
+    pa.bbox = reinterpret_cast<uint4 *>(h->bbox.p);
+    HIP_TRY(launch_prep(pa, s));
+
+    // ---- voxelize ---------------------------------------------------------------------------------
+    VoxArgs va;
+    va.rec = pa.rec;
+    va.bbox = pa.bbox;
+    va.offsets = d_off;
+    va.features = (r.mode == MODE_FEATURES) ? reinterpret_cast<const float *>(d_chan) : nullptr;
+    va.Tc = d_Tc;
+    va.kc = d_kc;
+    va.out = d_out;
+    va.res = g.res;
+    va.half = g.half;
+    va.D = D;
+    va.C = r.C;
+    va.B = r.B;
+    const int nz4 = (D + 3) / 4;
+    int nzc = (nz4 + 15) / 16;
+    int NW = (nz4 + nzc - 1) / nzc;
+    if (h->force_nw > 0 && h->force_nw <= 16) {
+        NW = std::min(h->force_nw, nz4);
+        nzc = (nz4 + NW - 1) / NW;
+    }
+    va.nsx = nz4;
+    va.nzc = nzc;
+    va.NW = NW;
+    va.ncc = (r.C + 31) / 32;
+    va.mode = r.mode;
+    va.vec_store = (D % 4 == 0) ? 1 : 0;
+    const int ct = pick_ct(std::min(r.C, 32));
+    (void)voxelize_lds_bytes(ct, NW, &va.dcap, &va.lds_union_bytes);
+    // a 4^3 sub-tile lies inside one reference block when 4 | blockdim (or there is a single block):
+    // the block cull is then wave-uniform and already folded into the candidate ranges.
+    const bool lane_range = !(g.nb == 1 || g.bd % 4 == 0);
+    if (h->profiling) HIP_TRY(hipEventRecord(h->ev0, s));
+    HIP_TRY(launch_voxelize(va, ct, gauss, chanwise, lane_range, s));
+    if (h->profiling) {
+        HIP_TRY(hipEventRecord(h->ev1, s));
+        h->timed = true;
+    }
+
+    HIP_TRY(hipEventRecord(slot->done, s));
+    slot->in_flight = true;
+
+    if (r.out_kind == MVX_HOST) {
+        HIP_TRY(hipMemcpyAsync(r.out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return MVX_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int mvx_version(void) { return MVX_VERSION; }
+
+const char *mvx_last_error(void) { return g_err.c_str(); }
+
+int mvx_device_count(int *count) {
+    if (!count) return fail(MVX_ERR_INVALID, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail_hip(e, "hipGetDeviceCount");
+    }
+    *count = n;
+    return MVX_OK;
+}
+
+int mvx_create(const mvx_config *cfg, mvx_handle **out) {
+    if (!cfg || !out) return fail(MVX_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (!(cfg->resolution > 0.0)) return fail(MVX_ERR_INVALID, "resolution must be > 0");
+    if (cfg->dimension < 1 || cfg->dimension > 4096) return fail(MVX_ERR_INVALID, "dimension must be in [1, 4096]");
+    if (cfg->density != MVX_GAUSSIAN && cfg->density != MVX_BINARY) return fail(MVX_ERR_INVALID, "bad density");
+    if (cfg->density == MVX_GAUSSIAN && !(cfg->sigma > 0.0)) return fail(MVX_ERR_INVALID, "sigma must be > 0");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_err = std::string("no usable HIP device (libmvx_hip has no CPU fallback): ") +
+                (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return MVX_ERR_NO_DEVICE;
+    }
+    if (cfg->device < 0 || cfg->device >= n) return fail(MVX_ERR_INVALID, "device ordinal out of range");
+    mvx_handle *h = new (std::nothrow) mvx_handle();
+    if (!h) return fail(MVX_ERR_ALLOC, "out of host memory");
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    make_geom(h);
+    if (const char *env = std::getenv("MVX_NW")) h->force_nw = std::atoi(env);
+    DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) {
+        delete h;
+        return fail_hip(guard.err, "hipSetDevice");
+    }
+    if ((e = configure_kernels()) != hipSuccess) {
+        delete h;
+        return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    if ((e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+        delete h;
+        return fail_hip(e, "hipEventCreate");
+    }
+    *out = h;
+    return MVX_OK;
+}
+
+int mvx_destroy(mvx_handle *h) {
+    if (!h) return MVX_OK;
+    DeviceGuard guard(h->device);
+    (void)hipDeviceSynchronize();
+    DevBuf *bufs[] = {&h->rec, &h->bbox, &h->meta, &h->aux, &h->in_coords, &h->in_chan, &h->in_radii, &h->out_stage};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (PinnedSlot &s : h->slots) {
+        if (s.p) (void)hipHostFree(s.p);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+    return MVX_OK;
+}
+
+int mvx_set_density(mvx_handle *h, int32_t density, double sigma) {
+    if (!h) return fail(MVX_ERR_INVALID, "null handle");
+    if (density != MVX_GAUSSIAN && density != MVX_BINARY) return fail(MVX_ERR_INVALID, "bad density");
+    if (density == MVX_GAUSSIAN && !(sigma > 0.0)) return fail(MVX_ERR_INVALID, "sigma must be > 0");
+    h->cfg.density = density;
+    if (density == MVX_GAUSSIAN) {
+        h->cfg.sigma = sigma;
+        h->sigma32 = (float)sigma;
+    }
+    return MVX_OK;
+}
+
+int mvx_forward_features_batch(mvx_handle *h, const double *coords, const float *features, const float *radii,
+                               double radius_scalar, int32_t radii_type, const int64_t *offsets,
+                               const mvx_xform *xforms, int32_t B, int32_t C, float *out, int32_t in_kind,
+                               int32_t out_kind, void *stream) {
+    RunArgs r{MODE_FEATURES, coords, features, radii, radius_scalar, radii_type, offsets, xforms, B, C, out,
+              in_kind, out_kind, reinterpret_cast<hipStream_t>(stream)};
+    return run(h, r);
+}
+
+int mvx_forward_types_batch(mvx_handle *h, const double *coords, const int32_t *types, const float *radii,
+                            double radius_scalar, int32_t radii_type, const int64_t *offsets,
+                            const mvx_xform *xforms, int32_t B, int32_t C, float *out, int32_t in_kind,
+                            int32_t out_kind, void *stream) {
+    RunArgs r{MODE_TYPES, coords, types, radii, radius_scalar, radii_type, offsets, xforms, B, C, out,
+              in_kind, out_kind, reinterpret_cast<hipStream_t>(stream)};
+    return run(h, r);
+}
+
+int mvx_forward_single_batch(mvx_handle *h, const double *coords, const float *radii, double radius_scalar,
+                             int32_t radii_type, const int64_t *offsets, const mvx_xform *xforms, int32_t B,
+                             float *out, int32_t in_kind, int32_t out_kind, void *stream) {
+    RunArgs r{MODE_SINGLE, coords, nullptr, radii, radius_scalar, radii_type, offsets, xforms, B, 1, out,
+              in_kind, out_kind, reinterpret_cast<hipStream_t>(stream)};
+    return run(h, r);
+}
+
+int mvx_forward_features(mvx_handle *h, const double *coords, const float *features, const float *radii,
+                         double radius_scalar, int32_t radii_type, int64_t N, int32_t C, const mvx_xform *xform,
+                         float *out, int32_t in_kind, int32_t out_kind, void *stream) {
+    const int64_t off[2] = {0, N};
+    return mvx_forward_features_batch(h, coords, features, radii, radius_scalar, radii_type, off, xform, 1, C, out,
+                                      in_kind, out_kind, stream);
+}
+
+int mvx_forward_types(mvx_handle *h, const double *coords, const int32_t *types, const float *radii,
+                      double radius_scalar, int32_t radii_type, int64_t N, int32_t C, const mvx_xform *xform,
+                      float *out, int32_t in_kind, int32_t out_kind, void *stream) {
+    const int64_t off[2] = {0, N};
+    return mvx_forward_types_batch(h, coords, types, radii, radius_scalar, radii_type, off, xform, 1, C, out,
+                                   in_kind, out_kind, stream);
+}
+
+int mvx_forward_single(mvx_handle *h, const double *coords, const float *radii, double radius_scalar,
+                       int32_t radii_type, int64_t N, const mvx_xform *xform, float *out, int32_t in_kind,
+                       int32_t out_kind, void *stream) {
+    const int64_t off[2] = {0, N};
+    return mvx_forward_single_batch(h, coords, radii, radius_scalar, radii_type, off, xform, 1, out, in_kind,
+                                    out_kind, stream);
+}
+
+int mvx_transform_coords(mvx_handle *h, const double *coords, int64_t N, const mvx_xform *xform, double *out,
+                         int32_t in_kind, int32_t out_kind, void *stream) {
+    if (!h || !xform || (N > 0 && (!coords || !out))) return fail(MVX_ERR_INVALID, "null argument");
+    if (N <= 0) return MVX_OK;
+    DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t xf_bytes = align_up(sizeof(mvx_xform), 16);
+    const size_t co_bytes = (size_t)N * 3 * sizeof(double);
+    const bool host_in = in_kind == MVX_HOST, host_out = out_kind == MVX_HOST;
+    PinnedSlot *slot = nullptr;
+    int rc = acquire_slot(h, xf_bytes + (host_in ? co_bytes : 0), &slot);
+    if (rc) return rc;
+    if ((rc = ensure(h->meta, xf_bytes))) return rc;
+    std::memcpy(slot->p, xform, sizeof(mvx_xform));
+    HIP_TRY(hipMemcpyAsync(h->meta.p, slot->p, xf_bytes, hipMemcpyHostToDevice, s));
+    const double *d_in = coords;
+    if (host_in) {
+        if ((rc = ensure(h->in_coords, co_bytes))) return rc;
+        std::memcpy(slot->p + xf_bytes, coords, co_bytes);
+        HIP_TRY(hipMemcpyAsync(h->in_coords.p, slot->p + xf_bytes, co_bytes, hipMemcpyHostToDevice, s));
+        d_in = reinterpret_cast<const double *>(h->in_coords.p);
+    }
+    double *d_out = out;
+    if (host_out) {
+        if ((rc = ensure(h->out_stage, co_bytes))) return rc;
+        d_out = reinterpret_cast<double *>(h->out_stage.p);
+    }
+    HIP_TRY(launch_transform(d_in, N, reinterpret_cast<const mvx_xform *>(h->meta.p), d_out, s));
+    HIP_TRY(hipEventRecord(slot->done, s));
+    slot->in_flight = true;
+    if (host_out) {
+        HIP_TRY(hipMemcpyAsync(out, d_out, co_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return MVX_OK;
+}
+
+int mvx_set_profiling(mvx_handle *h, int32_t enable) {
+    if (!h) return fail(MVX_ERR_INVALID, "null handle");
+    h->profiling = enable != 0;
+    h->timed = false;
+    return MVX_OK;
+}
+
+int mvx_last_kernel_ms(mvx_handle *h, float *ms) {
+    if (!h || !ms) return fail(MVX_ERR_INVALID, "null argument");
+    if (!h->timed) return fail(MVX_ERR_INVALID, "no timed launch (call mvx_set_profiling(h, 1) first)");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return MVX_OK;
+}
+
+int mvx_debug_read_records(mvx_handle *h, void *host_dst, int64_t n, void *stream) {
+    if (!h || !host_dst || n < 0) return fail(MVX_ERR_INVALID, "bad argument");
+    if ((size_t)n * sizeof(AtomRec) > h->rec.cap) return fail(MVX_ERR_INVALID, "more records requested than the workspace holds");
+    if (n == 0) return MVX_OK;
+    DeviceGuard guard(h->device);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(host_dst, h->rec.p, (size_t)n * sizeof(AtomRec), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return MVX_OK;
+}
+
+int mvx_alloc(mvx_handle *h, int64_t bytes, void **ptr) {
+    if (!h || !ptr || bytes < 0) return fail(MVX_ERR_INVALID, "bad argument");
+    DeviceGuard guard(h->device);
+    *ptr = nullptr;
+    hipError_t e = hipMalloc(ptr, (size_t)std::max<int64_t>(bytes, 16));
+    if (e != hipSuccess) {
+        g_err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return MVX_ERR_ALLOC;
+    }
+    return MVX_OK;
+}
+
+int mvx_free(mvx_handle *h, void *ptr) {
+    if (!h) return fail(MVX_ERR_INVALID, "null handle");
+    if (!ptr) return MVX_OK;
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipFree(ptr));
+    return MVX_OK;
+}
+
+int mvx_memcpy(mvx_handle *h, void *dst, const void *src, int64_t bytes, int32_t dst_kind, int32_t src_kind,
+               void *stream) {
+    if (!h || bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(MVX_ERR_INVALID, "bad argument");
+    if (bytes == 0) return MVX_OK;
+    DeviceGuard guard(h->device);
+    hipMemcpyKind kind;
+    if (dst_kind == MVX_DEVICE && src_kind == MVX_HOST) kind = hipMemcpyHostToDevice;
+    else if (dst_kind == MVX_HOST && src_kind == MVX_DEVICE) kind = hipMemcpyDeviceToHost;
+    else if (dst_kind == MVX_DEVICE && src_kind == MVX_DEVICE) kind = hipMemcpyDeviceToDevice;
+    else kind = hipMemcpyHostToHost;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, kind, s));
+    HIP_TRY(hipStreamSynchronize(s)); // host memory may be pageable: return only when the copy is done
+    return MVX_OK;
+}
+
+int mvx_memset_zero(mvx_handle *h, void *ptr, int64_t bytes, void *stream) {
+    if (!h || bytes < 0 || (bytes > 0 && !ptr)) return fail(MVX_ERR_INVALID, "bad argument");
+    if (bytes == 0) return MVX_OK;
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipMemsetAsync(ptr, 0, (size_t)bytes, reinterpret_cast<hipStream_t>(stream)));
+    return MVX_OK;
+}
+
+int mvx_stream_sync(mvx_handle *h, void *stream) {
+    if (!h) return fail(MVX_ERR_INVALID, "null handle");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    return MVX_OK;
+}
+
+} // extern "C"

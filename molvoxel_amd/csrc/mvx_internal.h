@@ -1,0 +1,84 @@
+// Internal declarations shared by the kernel TU (mvx_kernels.hip) and the C-ABI TU (mvx_capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mvx.h"
+
+namespace mvx {
+
+// Per-atom record written by the prep kernel and consumed by the voxelize kernel (64 B, AoS so
+// that one 16-lane dword load moves a whole record into LDS).
+struct __attribute__((aligned(16))) AtomRec {
+    double px, py, pz; // coordinates after centring / transform (fp64, reference op order)
+    double T;          // membership threshold on d2: contributes iff d2 <= T (exact restatement of
+                       // float32(float32(sqrt(d2))/r) <= 1); negative = never
+    float k;           // gaussian: value = exp2(k * d2), k = -0.5*log2(e)/(r*sigma)^2
+    int32_t type;      // forward_types channel
+    uint32_t xr, yr, zr; // admitted voxel index range per axis, lo | hi << 16 (inclusive); 0x0000ffff = empty
+    uint32_t pad[3];
+};
+static_assert(sizeof(AtomRec) == 64, "AtomRec must be 64 bytes");
+
+enum Mode { MODE_FEATURES = 0, MODE_TYPES = 1, MODE_SINGLE = 2 };
+// radius source seen by the prep kernel
+enum RadiiSrc { RAD_SCALAR = 0, RAD_ATOM = 1, RAD_CHANNEL_FEATURES = 2, RAD_CHANNEL_BY_TYPE = 3 };
+
+struct Geom {
+    double res;  // resolution
+    double half; // width / 2, width = res * (D - 1)
+    int32_t D;
+    int32_t bd;  // reference blockdim (cull emulation)
+    int32_t nb;  // ceil(D / bd)
+};
+
+struct PrepArgs {
+    const double *coords;   // (total, 3)
+    const float *radii;     // per RadiiSrc
+    const int32_t *types;   // (total,) or null
+    const int64_t *offsets; // device, B + 1
+    const mvx_xform *xforms; // device, B records, or null
+    const float *chan_aux;  // device: [0] = max channel radius (float32) for RAD_CHANNEL_FEATURES
+    int64_t total;
+    int32_t B;
+    int32_t C;
+    double radius_scalar;
+    int32_t radii_src;
+    int32_t density;
+    float sigma32;
+    Geom g;
+    AtomRec *rec;
+    uint4 *bbox; // {xr, yr, zr, 0} copy of the ranges, SoA for the slab scan
+};
+
+struct VoxArgs {
+    const AtomRec *rec;
+    const uint4 *bbox;
+    const int64_t *offsets;
+    const float *features; // (total, C) or null
+    const double *Tc;      // channel-wise features: per-channel d2 thresholds
+    const float *kc;       //                        per-channel gaussian coefficients
+    float *out;            // (B, C, D, D, D)
+    double res, half;
+    int32_t D, C, B;
+    int32_t nsx, nzc, ncc; // slabs per x/y axis, z chunks, channel chunks
+    int32_t NW;            // waves per workgroup = 4^3 sub-tiles per slab
+    int32_t mode;
+    int32_t vec_store;     // D % 4 == 0 and out 16-B aligned
+    int32_t dcap;          // candidate staging capacity (records)
+    int32_t lds_union_bytes;
+};
+
+// launchers (host side, mvx_kernels.hip)
+hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax,
+                           double *Tc, float *kc, hipStream_t s);
+hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
+hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf_dev, double *out, hipStream_t s);
+// ct: channels per thread (1, 4, 8, 16, 32); lane_range: per-lane index-range check needed
+hipError_t launch_voxelize(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
+hipError_t configure_kernels(); // raises the dynamic-LDS limit of every instantiation
+size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t *dcap, int32_t *union_bytes);
+
+constexpr int ICAP = 1024; // candidate index list capacity (>= max threads per workgroup)
+
+} // namespace mvx

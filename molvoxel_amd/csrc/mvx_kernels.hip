@@ -1,0 +1,573 @@
+// mvx_kernels.hip — hand-written gfx950 (MI355X / CDNA4) kernels of the voxelizer hot path.
+//
+// Replaces, on the device, the whole per-call body of the reference's
+//   Voxelizer.forward_features / forward_types / forward_single
+//   (molvoxel/voxelizer/numpy/voxelizer.py:97-169, 240-315, 370-436 and the helpers they call:
+//    _get_overlap :481-494, _get_overlap_blocks :496-527, _calc_grid :531-560,
+//    _set_grid_* :194-236, 344-366, 457-477; transform numpy/transform.py:44-60).
+// It is NOT a translation of that code (Python loop over 8^3 blocks, cdist -> (V,512) -> matmul) and
+// not of the torch path. Formulation: voxel-tile GATHER.
+//
+//   prep_kernel      one thread per atom: rigid transform in the reference's fp64 op order, exact
+//                    box cull + per-axis reference-block cull folded into an admitted voxel-index
+//                    range, exact membership threshold T on d2, gaussian coefficient k.
+//   voxelize_kernel  one workgroup per output slab of 4 x 4 x (4*NW) voxels (NW waves, one 4^3
+//                    sub-tile per wave, one voxel per lane, CT channel accumulators per lane in
+//                    registers). The workgroup scans the molecule's atom ranges for slab
+//                    candidates (ordered, ballot/prefix compaction), stages candidate records +
+//                    feature rows in LDS, every wave walks the candidates that touch its sub-tile
+//                    (fp64 d2, compare with T, exp2, packed FMAs), then the accumulators are
+//                    transposed through LDS and written with 16-B/lane stores in runs of full W
+//                    rows. Every output byte is written exactly once, zeros included (the
+//                    reference's overwrite semantics, numpy/voxelizer.py:133-135,158-160); no
+//                    atomics, no memset, no (V, DHW) intermediate, no MFMA (scatter-reduce).
+//
+// Exactness: membership float32(float32(sqrt_f64(d2))/r32) <= 1 is equivalent to d2 <= T with
+//   y  = largest fp64 whose float32 rounding is <= r32,  T = round_down(y * nextup(y))
+// (derivation in DESIGN.md §4; checked against 20k radii on the CPU and by tests/test_hip_parity.py).
+// d2 is formed exactly like scipy cdist: (dx*dx + dy*dy) + dz*dz in fp64 WITHOUT fma, so this TU
+// must be compiled with -ffp-contract=off and without fast-math.
+#include "mvx_internal.h"
+
+#include <math.h>
+
+// cdist-order arithmetic must not be fused, whatever flags the TU is built with.
+#pragma clang fp contract(off)
+
+namespace mvx {
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double next_up(double x) { // x > 0 finite
+    return __longlong_as_double(__double_as_longlong(x) + 1);
+}
+__device__ __forceinline__ double next_down(double x) { // x > 0 finite
+    return __longlong_as_double(__double_as_longlong(x) - 1);
+}
+
+// Largest fp64 d2 with float32(float32(sqrt(d2)) / r32) <= 1 (sqrt and division correctly rounded).
+__device__ double d2_threshold(float r32) {
+    if (!(r32 > 0.0f) || !(r32 < 3.0e38f)) return -1.0;
+    const float up = __uint_as_float(__float_as_uint(r32) + 1u);
+    const double m = 0.5 * ((double)r32 + (double)up); // midpoint between r32 and the next float (exact)
+    const bool even = (__float_as_uint(r32) & 1u) == 0u;
+    const double y = even ? m : next_down(m); // largest fp64 that rounds (ties-to-even) to <= r32
+    const double yp = next_up(y);
+    const double hi = y * yp;
+    const double lo = fma(y, yp, -hi); // exact residual of the product
+    return (lo >= 0.0) ? hi : next_down(hi);
+}
+
+__device__ __forceinline__ float gauss_coeff(float r32, float sigma32) {
+    const double rs = (double)r32 * (double)sigma32;
+    return (float)(-0.5 * 1.4426950408889634 / (rs * rs));
+}
+
+// do_transform in the reference's operation order (numpy/transform.py:44-60, _quaternion.py:24-50).
+__device__ void apply_xform(const mvx_xform &xf, double &x, double &y, double &z) {
+    if (xf.flags & MVX_XF_CENTER) {
+        x = x - xf.center[0];
+        y = y - xf.center[1];
+        z = z - xf.center[2];
+    }
+    const double t0 = (double)xf.trans[0], t1 = (double)xf.trans[1], t2 = (double)xf.trans[2];
+    if (xf.flags & MVX_XF_ROTATE) {
+        const double q0 = xf.quat[0], q1 = xf.quat[1], q2 = xf.quat[2], q3 = xf.quat[3];
+        const double zero = 0.0;
+        // qp = q * (0, x, y, z)
+        const double a0 = ((q0 * zero - q1 * x) - q2 * y) - q3 * z;
+        const double a1 = ((q0 * x + q1 * zero) + q2 * z) - q3 * y;
+        const double a2 = ((q0 * y - q1 * z) + q2 * zero) + q3 * x;
+        const double a3 = ((q0 * z + q1 * y) - q2 * x) + q3 * zero;
+        // qp * q^-1, q^-1 = (q0, -q1, -q2, -q3)
+        const double i0 = q0, i1 = q1 * -1, i2 = q2 * -1, i3 = q3 * -1;
+        x = ((a0 * i1 + a1 * i0) + a2 * i3) - a3 * i2;
+        y = ((a0 * i2 - a1 * i3) + a2 * i0) + a3 * i1;
+        z = ((a0 * i3 + a1 * i2) - a2 * i1) + a3 * i0;
+        if (xf.flags & MVX_XF_RECENTER) { // `coords += center` (numpy/transform.py:53)
+            x += xf.center[0];
+            y += xf.center[1];
+            z += xf.center[2];
+        }
+        if (xf.flags & MVX_XF_TRANSLATE) { // `coords += translation` inside the rotation branch
+            x += t0;
+            y += t1;
+            z += t2;
+        }
+    }
+    if (xf.flags & MVX_XF_TRANSLATE) { // ... and `coords = coords + translation` again (reference quirk Q4)
+        x = x + t0;
+        y = y + t1;
+        z = z + t2;
+    }
+}
+
+__device__ __forceinline__ int find_molecule(const int64_t *offsets, int B, int64_t a) {
+    int lo = 0, hi = B; // offsets[lo] <= a < offsets[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= a) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// channel-wise auxiliary: max radius (float32), per-channel thresholds / coefficients
+// ------------------------------------------------------------------------------------------------
+__global__ void chan_aux_kernel(const float *radii, int C, int density, float sigma32, float *rmax, double *Tc,
+                                float *kc) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float r = radii[c];
+        Tc[c] = d2_threshold(r);
+        kc[c] = density == MVX_GAUSSIAN ? gauss_coeff(r, sigma32) : 0.0f;
+    }
+    if (threadIdx.x == 0) {
+        float m = radii[0];
+        for (int c = 1; c < C; ++c) m = radii[c] > m ? radii[c] : m;
+        rmax[0] = m;
+    }
+}
+
+hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax, double *Tc,
+                           float *kc, hipStream_t s) {
+    hipLaunchKernelGGL(chan_aux_kernel, dim3(1), dim3(256), 0, s, radii, C, density, sigma32, rmax, Tc, kc);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: per-atom records
+// ------------------------------------------------------------------------------------------------
+// Admitted reference-block interval along one axis, as voxel indices (numpy/voxelizer.py:500-513):
+// block b admits the atom iff (b == 0 or p > bounds[b-1] - r) and (b == nb-1 or p < bounds[b] + r),
+// bounds[m] = axis[(m+1)*bd] + res/2 (numpy/voxelizer.py:55). Both conditions are monotone in b, so
+// the admitted set is the interval [#(p >= bounds[m] + r), #(p > bounds[m] - r)].
+__device__ __forceinline__ void block_interval(const Geom &g, double p, double r, int &vlo, int &vhi) {
+    int bhi = 0, blo = 0;
+    const double hres = g.res / 2.0;
+    for (int m = 0; m < g.nb - 1; ++m) {
+        const double ax = (double)((m + 1) * g.bd) * g.res - g.half;
+        const double bound = ax + hres;
+        if (p > bound - r) ++bhi;
+        if (!(p < bound + r)) ++blo;
+    }
+    vlo = blo * g.bd;
+    vhi = (bhi + 1) * g.bd - 1;
+    if (vhi > g.D - 1) vhi = g.D - 1;
+}
+
+// lo = 0xffff, hi = 0: fails every overlap test (lo <= box_hi needs box_hi >= 65535, beyond any grid)
+constexpr uint32_t EMPTY_RANGE = 0x0000ffffu;
+
+__global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= A.total) return;
+    const int b = find_molecule(A.offsets, A.B, a);
+    double p[3] = {A.coords[3 * a], A.coords[3 * a + 1], A.coords[3 * a + 2]};
+    if (A.xforms) apply_xform(A.xforms[b], p[0], p[1], p[2]);
+
+    const Geom g = A.g;
+    const double ub = g.half, lb = -1 * g.half;
+    float r32;   // membership radius (float32, as np.divide sees it)
+    double rc;   // fp64 radius the culls use
+    float rwin;  // widest radius for the conservative index window
+    bool keep = true;
+    int32_t type = 0;
+    if (A.types) {
+        type = A.types[a];
+        if (type < 0 || type >= A.C) keep = false; // never index radii / channels out of range
+    }
+    if (A.radii_src == RAD_SCALAR) {
+        rc = A.radius_scalar;
+        r32 = (float)A.radius_scalar;
+        rwin = r32;
+        for (int i = 0; i < 3; ++i) keep = keep && (p[i] > lb - rc) && (p[i] < ub + rc); // numpy/voxelizer.py:487-488
+    } else if (A.radii_src == RAD_CHANNEL_FEATURES) {
+        const float rmax = A.chan_aux[0];
+        r32 = rmax;
+        rwin = rmax;
+        rc = (double)rmax;
+        // np.float32 scalar: (python float -/+ float32) is evaluated in float32 (NEP 50), numpy/voxelizer.py:138
+        const double lo = (double)((float)lb - rmax), hi = (double)((float)ub + rmax);
+        for (int i = 0; i < 3; ++i) keep = keep && (p[i] > lo) && (p[i] < hi);
+    } else {
+        r32 = (A.radii_src == RAD_ATOM) ? A.radii[a] : (keep ? A.radii[type] : 0.0f); // numpy/voxelizer.py:284-285
+        rwin = r32;
+        rc = (double)r32;
+        for (int i = 0; i < 3; ++i) keep = keep && (p[i] + rc > lb) && (p[i] - rc < ub); // numpy/voxelizer.py:491-492
+    }
+
+    AtomRec R;
+    R.px = p[0];
+    R.py = p[1];
+    R.pz = p[2];
+    R.T = d2_threshold(r32);
+    R.k = (A.density == MVX_GAUSSIAN) ? gauss_coeff(r32, A.sigma32) : 0.0f;
+    R.type = type;
+    R.pad[0] = R.pad[1] = R.pad[2] = 0;
+    keep = keep && (R.T >= 0.0);
+
+    uint32_t rng[3] = {EMPTY_RANGE, EMPTY_RANGE, EMPTY_RANGE};
+    if (keep) {
+        const double rr = (double)rwin * 1.000001 + 1e-9;
+        for (int i = 0; i < 3; ++i) {
+            // conservative window of voxels that can be within the radius (membership is decided per voxel)
+            double flo = floor((p[i] - rr + g.half) / g.res) - 1.0;
+            double fhi = ceil((p[i] + rr + g.half) / g.res) + 1.0;
+            flo = flo < 0.0 ? 0.0 : flo;
+            fhi = fhi > (double)(g.D - 1) ? (double)(g.D - 1) : fhi;
+            if (!(flo <= fhi)) {
+                keep = false;
+                break;
+            }
+            int lo = (int)flo, hi = (int)fhi;
+            if (g.nb > 1) { // exact reference-block cull
+                int vlo, vhi;
+                block_interval(g, p[i], rc, vlo, vhi);
+                lo = lo > vlo ? lo : vlo;
+                hi = hi < vhi ? hi : vhi;
+            }
+            if (lo > hi) {
+                keep = false;
+                break;
+            }
+            rng[i] = (uint32_t)lo | ((uint32_t)hi << 16);
+        }
+    }
+    if (!keep) rng[0] = rng[1] = rng[2] = EMPTY_RANGE;
+    R.xr = rng[0];
+    R.yr = rng[1];
+    R.zr = rng[2];
+    A.rec[a] = R;
+    A.bbox[a] = make_uint4(rng[0], rng[1], rng[2], 0u);
+}
+
+hipError_t launch_prep(const PrepArgs &a, hipStream_t s) {
+    if (a.total <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((a.total + 255) / 256);
+    hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) transform_kernel(const double *coords, int64_t N, const mvx_xform *xf,
+                                                         double *out) {
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= N) return;
+    double x = coords[3 * a], y = coords[3 * a + 1], z = coords[3 * a + 2];
+    apply_xform(xf[0], x, y, z);
+    out[3 * a] = x;
+    out[3 * a + 1] = y;
+    out[3 * a + 2] = z;
+}
+
+hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf_dev, double *out, hipStream_t s) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(transform_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, coords, N, xf_dev, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// voxelize
+// ------------------------------------------------------------------------------------------------
+// LDS map (dynamic, 16-B aligned base):
+//   [0, 4*ICAP)            int   list[ICAP]      candidate atom indices of the slab, atom order
+//   [LDS_WCNT, +128)       int   wcnt[2][16]     per-wave match counts (double-buffered)
+//   [LDS_UNION, ...)       union {
+//        candidates:  uint32 zr[dcap] | records: dcap x (64 + 4*CT) bytes (AtomRec image + CT feature floats)
+//        out tile:    (CT*16) rows x RS floats,  RS = 4*NW + pad,  row = (c, x, y), pad keeps ds_write_b32
+//                     conflict-free: (RS/4) odd  }
+constexpr int LDS_WCNT = 4 * ICAP;
+constexpr int LDS_UNION = LDS_WCNT + 128;
+
+__host__ __device__ __forceinline__ int row_stride_floats(int NW) { return 4 * NW + ((NW & 1) ? 8 : 4); }
+
+size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t *dcap, int32_t *union_bytes) {
+    const int stride = 64 + (ct < 4 ? 16 : 4 * ct);
+    const size_t tile = (size_t)ct * 16 * row_stride_floats(NW) * 4;
+    size_t un = tile;
+    const size_t min_cand = (size_t)64 * (stride + 4) + 16;
+    if (un < min_cand) un = min_cand;
+    int cap = (int)((un - 16) / (stride + 4));
+    if (cap > ICAP) cap = ICAP;
+    cap &= ~3; // keeps the record base 16-B aligned
+    *dcap = cap;
+    *union_bytes = (int32_t)un;
+    return (size_t)LDS_UNION + un;
+}
+
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+__global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *list = reinterpret_cast<int *>(smem);
+    int *wcnt = reinterpret_cast<int *>(smem + LDS_WCNT);
+    char *un = smem + LDS_UNION;
+
+    constexpr int STRIDE = 64 + (CT < 4 ? 16 : 4 * CT); // multiple of 16 B
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = A.NW;
+    const int nthreads = NW * 64;
+    const int D = A.D;
+
+    // ---- block -> (molecule, channel chunk, slab) -------------------------------------------------
+    int bid = blockIdx.x;
+    const int zc = bid % A.nzc;
+    bid /= A.nzc;
+    const int sy = bid % A.nsx;
+    bid /= A.nsx;
+    const int sx = bid % A.nsx;
+    bid /= A.nsx;
+    const int cc = bid % A.ncc;
+    const int b = bid / A.ncc;
+    const int cbase = cc * 32;
+
+    const int x0 = 4 * sx, y0 = 4 * sy, z0 = zc * 4 * NW;
+    const int zhi_slab = z0 + 4 * NW - 1;
+    const int64_t a0 = A.offsets[b], a1 = A.offsets[b + 1];
+
+    // ---- this lane's voxel ---------------------------------------------------------------------
+    const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
+    const int ix = x0 + lx, iy = y0 + ly, iz = z0 + 4 * wave + lz;
+    const double gx = (double)ix * A.res - A.half; // axis[i] = i*res - width/2, numpy/voxelizer.py:41-43
+    const double gy = (double)iy * A.res - A.half;
+    const double gz = (double)iz * A.res - A.half;
+    const int zlo_w = z0 + 4 * wave, zhi_w = zlo_w + 3;
+
+    float2v acc[(CT + 1) / 2];
+#pragma unroll
+    for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
+
+    bool any_candidate = false;
+    int64_t cursor = a0;
+    int phase = 0;
+    while (cursor < a1) {
+        // ---- 1. ordered scan of the molecule's atom ranges against the slab box -----------------
+        int nlist = 0;
+        while (cursor < a1 && nlist + nthreads <= ICAP) {
+            const int64_t a = cursor + tid;
+            bool m = false;
+            if (a < a1) {
+                const uint4 bb = A.bbox[a];
+                const int xl = bb.x & 0xffff, xh = bb.x >> 16, yl = bb.y & 0xffff, yh = bb.y >> 16;
+                const int zl = bb.z & 0xffff, zh = bb.z >> 16;
+                m = (xl <= x0 + 3) && (xh >= x0) && (yl <= y0 + 3) && (yh >= y0) && (zl <= zhi_slab) && (zh >= z0);
+            }
+            const unsigned long long mask = __ballot(m);
+            int *wc = wcnt + (phase & 1) * 16;
+            if (lane == 0) wc[wave] = __popcll(mask);
+            __syncthreads();
+            int pre = 0, tot = 0;
+            for (int w = 0; w < NW; ++w) {
+                const int c = wc[w];
+                pre += (w < wave) ? c : 0;
+                tot += c;
+            }
+            if (m) {
+                const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                list[nlist + pre + below] = (int)(a - a0);
+            }
+            nlist += tot;
+            cursor += nthreads;
+            ++phase;
+        }
+        __syncthreads(); // list complete
+        if (nlist == 0) continue;
+        any_candidate = true;
+
+        // ---- 2./3. stage candidates in chunks of dcap, accumulate ------------------------------
+        for (int c0 = 0; c0 < nlist; c0 += A.dcap) {
+            const int n = (nlist - c0) < A.dcap ? (nlist - c0) : A.dcap;
+            unsigned *zr_l = reinterpret_cast<unsigned *>(un);
+            char *cand = un + (((size_t)A.dcap * 4 + 15) & ~(size_t)15);
+            for (int j = wave; j < n; j += NW) {
+                const int64_t a = a0 + list[c0 + j];
+                const unsigned *src = reinterpret_cast<const unsigned *>(A.rec + a);
+                unsigned *dst = reinterpret_cast<unsigned *>(cand + (size_t)j * STRIDE);
+                if (lane < 16) {
+                    const unsigned v = src[lane];
+                    dst[lane] = v;
+                    if (lane == 12) zr_l[j] = v; // AtomRec::zr
+                } else if (lane < 16 + CT) {
+                    const int c = lane - 16;
+                    float f = 0.0f;
+                    if (cbase + c < A.C) {
+                        if (A.mode == MODE_FEATURES) f = A.features[a * A.C + cbase + c];
+                        else if (A.mode == MODE_TYPES) f = (A.rec[a].type == cbase + c) ? 1.0f : 0.0f;
+                        else f = 1.0f;
+                    }
+                    reinterpret_cast<float *>(dst)[lane] = f;
+                }
+            }
+            __syncthreads();
+
+            for (int jb = 0; jb < n; jb += 64) {
+                const int j = jb + lane;
+                bool ok = false;
+                if (j < n) {
+                    const unsigned zr = zr_l[j];
+                    ok = ((int)(zr & 0xffff) <= zhi_w) && ((int)(zr >> 16) >= zlo_w);
+                }
+                unsigned long long mask = __ballot(ok);
+                while (mask) {
+                    const int jj = jb + __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const char *r = cand + (size_t)jj * STRIDE;
+                    const double2 Pxy = *reinterpret_cast<const double2 *>(r);      // px, py
+                    const double2 PzT = *reinterpret_cast<const double2 *>(r + 16); // pz, T
+                    const double dx = Pxy.x - gx, dy = Pxy.y - gy, dz = PzT.x - gz;
+                    const double d2 = (dx * dx + dy * dy) + dz * dz; // cdist order, no fma
+                    bool hit = d2 <= PzT.y;
+                    if (LANE_RANGE) {
+                        const uint4 q = *reinterpret_cast<const uint4 *>(r + 32); // k, type, xr, yr
+                        hit = hit && (ix >= (int)(q.z & 0xffff)) && (ix <= (int)(q.z >> 16)) &&
+                              (iy >= (int)(q.w & 0xffff)) && (iy <= (int)(q.w >> 16));
+                        const unsigned zr = *reinterpret_cast<const unsigned *>(r + 48);
+                        hit = hit && (iz >= (int)(zr & 0xffff)) && (iz <= (int)(zr >> 16));
+                    }
+                    if (__ballot(hit) == 0ull) continue;
+                    const float *f = reinterpret_cast<const float *>(r + 64);
+                    const float d2f = (float)d2;
+                    if (!CHANWISE) {
+                        float val = 0.0f;
+                        if (hit) val = GAUSS ? __builtin_amdgcn_exp2f(*reinterpret_cast<const float *>(r + 32) * d2f) : 1.0f;
+                        const float2v v2 = (float2v){val, val};
+                        if (CT == 1) {
+                            acc[0].x = fmaf(val, f[0], acc[0].x);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < CT / 2; ++c) {
+                                const float2v f2 = *reinterpret_cast<const float2v *>(f + 2 * c);
+                                acc[c] = __builtin_elementwise_fma(v2, f2, acc[c]);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) {
+                            const int ch = cbase + c;
+                            float val = 0.0f;
+                            if (ch < A.C && hit && d2 <= A.Tc[ch])
+                                val = GAUSS ? __builtin_amdgcn_exp2f(A.kc[ch] * d2f) : 1.0f;
+                            if (c & 1) acc[c / 2].y = fmaf(val, f[c], acc[c / 2].y);
+                            else acc[c / 2].x = fmaf(val, f[c], acc[c / 2].x);
+                        }
+                    }
+                }
+            }
+            __syncthreads(); // candidates consumed: the union region may be rewritten
+        }
+    }
+
+    // ---- 4. write-out ----------------------------------------------------------------------------
+    const int RS = row_stride_floats(NW);
+    const size_t D2 = (size_t)D * D;
+    const int q = tid % NW;         // float4 slot inside a row
+    const int rfirst = tid / NW;    // first row of this thread; rows advance by 64 per pass
+    const int zq = z0 + 4 * q;
+    const int nrows = CT * 16;
+    float *obase = A.out + ((size_t)b * A.C + cbase) * D2 * D;
+    if (!any_candidate) {
+        // empty slab: pure zero fill with the same addressing (no LDS round trip)
+        for (int R = rfirst; R < nrows; R += 64) {
+            const int c = R >> 4, x = (R >> 2) & 3, y = R & 3;
+            if (cbase + c >= A.C || x0 + x >= D || y0 + y >= D || zq >= D) continue;
+            float *dst = obase + (size_t)c * D2 * D + (size_t)(x0 + x) * D2 + (size_t)(y0 + y) * D + zq;
+            if (A.vec_store) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (zq + e < D) dst[e] = 0.0f;
+            }
+        }
+        return;
+    }
+    float *tile = reinterpret_cast<float *>(un);
+    {
+        const int col = 4 * wave + lz;
+        const int rxy = lx * 4 + ly;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float v = (c & 1) ? acc[c / 2].y : acc[c / 2].x;
+            tile[(c * 16 + rxy) * RS + col] = v;
+        }
+    }
+    __syncthreads();
+    for (int R = rfirst; R < nrows; R += 64) {
+        const int c = R >> 4, x = (R >> 2) & 3, y = R & 3;
+        if (cbase + c >= A.C || x0 + x >= D || y0 + y >= D || zq >= D) continue;
+        const float4 v = *reinterpret_cast<const float4 *>(tile + R * RS + 4 * q);
+        float *dst = obase + (size_t)c * D2 * D + (size_t)(x0 + x) * D2 + (size_t)(y0 + y) * D + zq;
+        if (A.vec_store) {
+            *reinterpret_cast<float4 *>(dst) = v;
+        } else {
+            const float e4[4] = {v.x, v.y, v.z, v.w};
+            for (int e = 0; e < 4; ++e)
+                if (zq + e < D) dst[e] = e4[e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch
+// ------------------------------------------------------------------------------------------------
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+static hipError_t launch_one(const VoxArgs &a, size_t lds, hipStream_t s) {
+    const long long blocks = (long long)a.B * a.ncc * a.nsx * a.nsx * a.nzc;
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL((voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE>), dim3((unsigned)blocks), dim3(a.NW * 64),
+                       lds, s, a);
+    return hipGetLastError();
+}
+
+template <int CT>
+static hipError_t launch_ct(const VoxArgs &a, bool gauss, bool chanwise, bool lane_range, size_t lds, hipStream_t s) {
+    if (chanwise) return gauss ? launch_one<CT, true, true, true>(a, lds, s) : launch_one<CT, false, true, true>(a, lds, s);
+    if (lane_range) return gauss ? launch_one<CT, true, false, true>(a, lds, s) : launch_one<CT, false, false, true>(a, lds, s);
+    return gauss ? launch_one<CT, true, false, false>(a, lds, s) : launch_one<CT, false, false, false>(a, lds, s);
+}
+
+hipError_t launch_voxelize(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {
+    int32_t dcap, ub;
+    const size_t lds = voxelize_lds_bytes(ct, a.NW, &dcap, &ub);
+    switch (ct) {
+    case 1: return launch_ct<1>(a, gauss, chanwise, lane_range, lds, s);
+    case 4: return launch_ct<4>(a, gauss, chanwise, lane_range, lds, s);
+    case 8: return launch_ct<8>(a, gauss, chanwise, lane_range, lds, s);
+    case 16: return launch_ct<16>(a, gauss, chanwise, lane_range, lds, s);
+    case 32: return launch_ct<32>(a, gauss, chanwise, lane_range, lds, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+static hipError_t raise_lds() {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+template <int CT>
+static hipError_t raise_lds_ct() {
+    hipError_t e;
+    if ((e = raise_lds<CT, true, true, true>()) != hipSuccess) return e;
+    if ((e = raise_lds<CT, false, true, true>()) != hipSuccess) return e;
+    if ((e = raise_lds<CT, true, false, true>()) != hipSuccess) return e;
+    if ((e = raise_lds<CT, false, false, true>()) != hipSuccess) return e;
+    if ((e = raise_lds<CT, true, false, false>()) != hipSuccess) return e;
+    return raise_lds<CT, false, false, false>();
+}
+
+hipError_t configure_kernels() {
+    hipError_t e;
+    if ((e = raise_lds_ct<1>()) != hipSuccess) return e;
+    if ((e = raise_lds_ct<4>()) != hipSuccess) return e;
+    if ((e = raise_lds_ct<8>()) != hipSuccess) return e;
+    if ((e = raise_lds_ct<16>()) != hipSuccess) return e;
+    return raise_lds_ct<32>();
+}
+
+} // namespace mvx

@@ -1,0 +1,100 @@
+"""ctypes binding of libmvx_hip.so (the C ABI declared in include/mvx.h).
+
+There is deliberately no fallback: if the shared library is missing or cannot be loaded the
+import of the HIP backend fails loudly. Build it with `make -C molvoxel_amd/csrc` (or
+`python -c "import __graft_entry__ as g; g.build()"`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "csrc")
+LIB_PATH = os.path.join(CSRC, "libmvx_hip.so")
+
+MVX_HOST, MVX_DEVICE = 0, 1
+MVX_GAUSSIAN, MVX_BINARY = 0, 1
+MVX_RADII_SCALAR, MVX_RADII_ATOM, MVX_RADII_CHANNEL = 0, 1, 2
+MVX_XF_CENTER, MVX_XF_ROTATE, MVX_XF_TRANSLATE, MVX_XF_RECENTER = 1, 2, 4, 8
+
+
+class MvxConfig(C.Structure):
+    _fields_ = [
+        ("resolution", C.c_double),
+        ("sigma", C.c_double),
+        ("dimension", C.c_int32),
+        ("blockdim", C.c_int32),
+        ("density", C.c_int32),
+        ("device", C.c_int32),
+    ]
+
+
+class MvxXform(C.Structure):
+    _fields_ = [
+        ("center", C.c_double * 3),
+        ("quat", C.c_double * 4),
+        ("trans", C.c_float * 3),
+        ("flags", C.c_uint32),
+    ]
+
+
+Handle = C.c_void_p
+_vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+
+# name -> (restype, argtypes); pointers to caller data are passed as integers (void*)
+SIGNATURES = {
+    "mvx_version": (C.c_int, []),
+    "mvx_last_error": (C.c_char_p, []),
+    "mvx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mvx_create": (C.c_int, [C.POINTER(MvxConfig), C.POINTER(Handle)]),
+    "mvx_destroy": (C.c_int, [Handle]),
+    "mvx_set_density": (C.c_int, [Handle, _i32, _dbl]),
+    "mvx_forward_features_batch": (C.c_int, [Handle, _vp, _vp, _vp, _dbl, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "mvx_forward_types_batch": (C.c_int, [Handle, _vp, _vp, _vp, _dbl, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "mvx_forward_single_batch": (C.c_int, [Handle, _vp, _vp, _dbl, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
+    "mvx_forward_features": (C.c_int, [Handle, _vp, _vp, _vp, _dbl, _i32, _i64, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "mvx_forward_types": (C.c_int, [Handle, _vp, _vp, _vp, _dbl, _i32, _i64, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "mvx_forward_single": (C.c_int, [Handle, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _i32, _i32, _vp]),
+    "mvx_transform_coords": (C.c_int, [Handle, _vp, _i64, _vp, _vp, _i32, _i32, _vp]),
+    "mvx_set_profiling": (C.c_int, [Handle, _i32]),
+    "mvx_last_kernel_ms": (C.c_int, [Handle, C.POINTER(C.c_float)]),
+    "mvx_debug_read_records": (C.c_int, [Handle, _vp, _i64, _vp]),
+    "mvx_alloc": (C.c_int, [Handle, _i64, C.POINTER(C.c_void_p)]),
+    "mvx_free": (C.c_int, [Handle, _vp]),
+    "mvx_memcpy": (C.c_int, [Handle, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "mvx_memset_zero": (C.c_int, [Handle, _vp, _i64, _vp]),
+    "mvx_stream_sync": (C.c_int, [Handle, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmvx_hip.so once; raise (never fall back) when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP voxelizer has no CPU fallback. "
+            "Build it with `make -C molvoxel_amd/csrc` (needs hipcc, --offload-arch=gfx950)."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().mvx_last_error()
+        raise RuntimeError(f"libmvx_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load().mvx_device_count(C.byref(n))
+    return n.value if rc == 0 else 0

@@ -1,0 +1,463 @@
+"""`library='hip'` backend: the reference's Voxelizer interface on hand-written MI355X kernels.
+
+Host layer only: argument checks (same AssertionError messages as the reference numpy backend,
+molvoxel/voxelizer/numpy/voxelizer.py:171-192, 317-342, 438-455), dtype fixes (:125-130, :268-271),
+channel-count inference (:275-278), RNG draws for the random transform in the reference's order
+(numpy/transform.py:63-80) and the call through the C ABI (include/mvx.h). All arithmetic of the
+hot path — centring, rigid transform, culls, distances, densities, accumulation — runs on the GPU.
+There is no CPU fallback: construction fails without the shared library or without a HIP device.
+
+Array arguments may be numpy arrays (host: staged through pinned memory by the library) or torch
+CUDA tensors on this voxelizer's device (zero-copy via data_ptr on the current torch stream).
+Grids this backend allocates are torch CUDA tensors by default (`output="torch"`), so results stay
+in HBM; pass `output="numpy"` (or a numpy `out_grid`) for host arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ..base import BaseVoxelizer
+from . import _lib
+from .transform import RandomTransform, draw_forward_transform
+
+try:  # torch is plumbing (device memory + streams); the library also works without it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_torch(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _np_isscalar(x) -> bool:
+    return np.isscalar(x)
+
+
+class Voxelizer(BaseVoxelizer):
+    LIB = "HIP"
+    transform_class = RandomTransform
+
+    def __init__(
+        self,
+        resolution: float = 0.5,
+        dimension: int = 64,
+        radii_type: str = "scalar",
+        density_type: str = "gaussian",
+        precision: int = 32,
+        blockdim: int | None = None,
+        device=None,
+        output: str = "torch",
+        **kwargs,
+    ):
+        super().__init__(resolution, dimension, radii_type, density_type, **kwargs)
+        assert precision in [32, 64]
+        if precision != 32:
+            raise NotImplementedError("precision=64 grids are not implemented by the HIP backend yet")
+        assert output in ("torch", "numpy")
+        if output == "torch" and torch is None:
+            raise ImportError("output='torch' needs PyTorch; use output='numpy'")
+        self.fp = np.float32
+        self.blockdim = blockdim if blockdim is not None else 8  # numpy/voxelizer.py:38
+        self.num_blocks = -(-dimension // self.blockdim)
+        self.output = output
+        self._lib = _lib.load()
+        self._device_index = self._resolve_device(device)
+        self._handle = _lib.Handle()
+        cfg = _lib.MvxConfig(
+            float(resolution),
+            float(getattr(self, "_sigma", 0.5)),
+            int(dimension),
+            int(self.blockdim),
+            _lib.MVX_GAUSSIAN if density_type == "gaussian" else _lib.MVX_BINARY,
+            self._device_index,
+        )
+        _lib.check(self._lib.mvx_create(C.byref(cfg), C.byref(self._handle)))
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _resolve_device(device) -> int:
+        if device is None or device == "cuda":
+            if torch is not None and torch.cuda.is_available():
+                return torch.cuda.current_device()
+            return 0
+        if isinstance(device, int):
+            return device
+        if torch is not None:
+            d = torch.device(device)
+            assert d.type == "cuda", "the HIP backend runs on a GPU device only"
+            return d.index if d.index is not None else torch.cuda.current_device()
+        raise ValueError(f"cannot interpret device={device!r}")
+
+    @property
+    def device(self):
+        return torch.device("cuda", self._device_index) if torch is not None else self._device_index
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                self._lib.mvx_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    def _density_changed(self):
+        if getattr(self, "_handle", None) is not None:
+            dens = _lib.MVX_GAUSSIAN if self.is_density_type_gaussian else _lib.MVX_BINARY
+            _lib.check(self._lib.mvx_set_density(self._handle, dens, float(getattr(self, "_sigma", 0.5))))
+
+    # ------------------------------------------------------------------------------------------
+    # allocation / conversion (numpy/voxelizer.py:60-70, 562-583)
+    def get_empty_grid(self, num_channels: int, batch_size: int | None = None, init_zero: bool = False):
+        shape = self.grid_dimension(num_channels)
+        if batch_size is not None:
+            shape = (batch_size,) + shape
+        if self.output == "torch":
+            fn = torch.zeros if init_zero else torch.empty
+            return fn(shape, dtype=torch.float32, device=self.device)
+        return (np.zeros if init_zero else np.empty)(shape, dtype=self.fp)
+
+    def asarray(self, array, obj: str):
+        if obj in ("coords", "center"):
+            np_dt, t_dt = np.float64, "float64"
+        elif obj in ("features", "radii"):
+            np_dt, t_dt = np.float32, "float32"
+        elif obj == "types":
+            np_dt, t_dt = np.int16, "int16"
+        else:
+            raise ValueError("obj should be ['coords', 'center', 'radii', types', 'features']")
+        if self.output == "torch":
+            if _is_torch(array):
+                return array.to(device=self.device, dtype=getattr(torch, t_dt))
+            return torch.as_tensor(np.asarray(array, dtype=np_dt), device=self.device)
+        if _is_torch(array):
+            array = array.detach().cpu().numpy()
+        return np.asarray(array, dtype=np_dt)
+
+    def to(self, device):
+        """torch-backend compatibility: a handle is bound to one GPU; moving re-creates it."""
+        idx = self._resolve_device(device)
+        if idx != self._device_index:
+            kw = {"sigma": self._sigma} if self.is_density_type_gaussian else {}
+            return type(self)(self._resolution, self._dimension, self._radii_type, self._density_type, 32,
+                              self.blockdim, idx, self.output, **kw)
+        return self
+
+    def cuda(self):
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    # argument plumbing
+    def _stream(self):
+        if torch is not None and torch.cuda.is_available():
+            return C.c_void_p(torch.cuda.current_stream(self._device_index).cuda_stream)
+        return C.c_void_p(0)
+
+    def _on_device(self, x) -> bool:
+        return _is_torch(x) and x.is_cuda and x.device.index == self._device_index
+
+    def _prepare_inputs(self, coords, chan, chan_kind, radii):
+        """Returns (coords, chan, radii_array_or_None, in_kind, keepalive). chan_kind in {features, types, None}."""
+        dev = self._on_device(coords)
+        keep = []
+        if dev:
+            c = coords.to(torch.float64).contiguous()
+            ch = None
+            if chan_kind == "features":
+                ch = (chan if _is_torch(chan) else torch.as_tensor(np.asarray(chan), device=self.device)).to(
+                    device=self.device, dtype=torch.float32).contiguous()
+            elif chan_kind == "types":
+                t = chan if _is_torch(chan) else torch.as_tensor(np.asarray(chan), device=self.device)
+                ch = t.to(device=self.device).to(torch.int16).to(torch.int32).contiguous()  # int16 like numpy/voxelizer.py:269
+            r = None
+            if not _np_isscalar(radii):
+                r = (radii if _is_torch(radii) else torch.as_tensor(np.asarray(radii), device=self.device)).to(
+                    device=self.device, dtype=torch.float32).contiguous()
+            keep += [c, ch, r]
+            return c, ch, r, _lib.MVX_DEVICE, keep
+        if _is_torch(coords):
+            coords = coords.detach().cpu().numpy()
+        c = np.ascontiguousarray(coords, dtype=np.float64)
+        ch = None
+        if chan_kind == "features":
+            ch = chan.detach().cpu().numpy() if _is_torch(chan) else np.asarray(chan)
+            ch = np.ascontiguousarray(ch, dtype=np.float32)
+        elif chan_kind == "types":
+            t = chan.detach().cpu().numpy() if _is_torch(chan) else np.asarray(chan)
+            ch = np.ascontiguousarray(t.astype(np.int16), dtype=np.int32)
+        r = None
+        if not _np_isscalar(radii):
+            r = radii.detach().cpu().numpy() if _is_torch(radii) else np.asarray(radii)
+            r = np.ascontiguousarray(r, dtype=np.float32)
+        keep += [c, ch, r]
+        return c, ch, r, _lib.MVX_HOST, keep
+
+    @staticmethod
+    def _ptr(x):
+        if x is None:
+            return C.c_void_p(0)
+        if _is_torch(x):
+            return C.c_void_p(x.data_ptr())
+        return C.c_void_p(x.ctypes.data)
+
+    def _make_xform(self, center, random_translation, random_rotation, coords_dtype_is_f32=False):
+        """One mvx_xform: centring + the random transform drawn in the reference's RNG order."""
+        xf = _lib.MvxXform()
+        flags = 0
+        if center is not None:
+            cen = center.detach().cpu().numpy() if _is_torch(center) else np.asarray(center)
+            cen = cen.reshape(3).astype(np.float64)
+            xf.center[:] = cen.tolist()
+            flags |= _lib.MVX_XF_CENTER
+        translation, quaternion = draw_forward_transform(random_translation, random_rotation)
+        if quaternion is not None:
+            xf.quat[:] = [float(q) for q in quaternion]
+            flags |= _lib.MVX_XF_ROTATE
+        if translation is not None:
+            xf.trans[:] = translation.reshape(3).tolist()
+            flags |= _lib.MVX_XF_TRANSLATE
+        xf.flags = flags
+        return xf
+
+    def _resolve_out(self, out_grid, shape):
+        """Returns (buffer passed to the library, out_kind, object to return)."""
+        if out_grid is None:
+            out_grid = self.get_empty_grid(shape[0])
+        if _is_torch(out_grid):
+            if self._on_device(out_grid) and out_grid.is_contiguous() and out_grid.dtype == torch.float32:
+                return out_grid, _lib.MVX_DEVICE, out_grid, None
+            tmp = torch.empty(tuple(out_grid.shape), dtype=torch.float32, device=self.device)
+            return tmp, _lib.MVX_DEVICE, out_grid, "copy_torch"
+        if out_grid.flags.c_contiguous and out_grid.dtype == np.float32:
+            return out_grid, _lib.MVX_HOST, out_grid, None
+        tmp = np.empty(out_grid.shape, dtype=np.float32)
+        return tmp, _lib.MVX_HOST, out_grid, "copy_numpy"
+
+    @staticmethod
+    def _finish_out(buf, ret, how):
+        if how == "copy_torch":
+            ret.copy_(buf)
+        elif how == "copy_numpy":
+            ret[...] = buf
+        return ret
+
+    def _radii_type_code(self):
+        if self.is_radii_type_scalar:
+            return _lib.MVX_RADII_SCALAR
+        if self.is_radii_type_atom_wise:
+            return _lib.MVX_RADII_ATOM
+        return _lib.MVX_RADII_CHANNEL
+
+    # ------------------------------------------------------------------------------------------
+    # VECTOR  (replaces numpy/voxelizer.py:97-236)
+    def forward_features(self, coords, center, features, radii, random_translation=0.0, random_rotation=False,
+                         out_grid=None):
+        """coords (V,3), center (3,) | None, features (V,C), radii scalar | (V,) | (C,); out (C,D,H,W)."""
+        self._check_args_features(coords, features, radii, out_grid)
+        C_ = features.shape[1]
+        c, f, r, in_kind, keep = self._prepare_inputs(coords, features, "features", radii)
+        xf = self._make_xform(center, random_translation, random_rotation)
+        buf, out_kind, ret, how = self._resolve_out(out_grid, (C_,))
+        rs = float(radii) if _np_isscalar(radii) else 0.0
+        _lib.check(self._lib.mvx_forward_features(
+            self._handle, self._ptr(c), self._ptr(f), self._ptr(r), rs, self._radii_type_code(), c.shape[0], C_,
+            C.cast(C.byref(xf), C.c_void_p), self._ptr(buf), in_kind, out_kind, self._stream()))
+        return self._finish_out(buf, ret, how)
+
+    def _check_args_features(self, coords, features, radii, out_grid=None):
+        V = coords.shape[0]
+        C_ = features.shape[1]
+        D = H = W = self.dimension
+        assert features.shape[0] == V, f"atom features does not match number of atoms: {features.shape[0]} vs {V}"
+        assert features.ndim == 2, f"atom features does not match dimension: {features.shape} vs {(V,'*')}"
+        if self.is_radii_type_scalar:
+            assert _np_isscalar(radii), "the radii type of voxelizer is `scalar`, radii should be scalar"
+        elif self.is_radii_type_channel_wise:
+            assert not _np_isscalar(radii), f"the radii type of voxelizer is `channel-wise`, radii should be Array[{C_},]"
+            assert tuple(radii.shape) == (C_,), f"radii does not match dimension (number of channels,): {tuple(radii.shape)} vs {(C_,)}"
+        else:
+            assert not _np_isscalar(radii), f"the radii type of voxelizer is `atom-wise`, radii should be Array[{V},]"
+            assert tuple(radii.shape) == (V,), f"radii does not match dimension (number of atoms,): {tuple(radii.shape)} vs {(V,)}"
+        if out_grid is not None:
+            assert tuple(out_grid.shape) == (C_, D, H, W), f"Output grid dimension incorrect: {tuple(out_grid.shape)} vs {(C_,D,H,W)}"
+
+    # ------------------------------------------------------------------------------------------
+    # INDEX  (replaces numpy/voxelizer.py:240-366)
+    def forward_types(self, coords, center, types, radii, random_translation=0.0, random_rotation=False,
+                      out_grid=None):
+        """coords (V,3), center (3,) | None, types (V,), radii scalar | (V,) | (C,); out (C,D,H,W)."""
+        n_types = self._check_args_types(coords, types, radii, out_grid)
+        if out_grid is not None:
+            C_ = out_grid.shape[0]  # extra channels stay zero (numpy/voxelizer.py:337)
+        elif self.is_radii_type_channel_wise:
+            C_ = radii.shape[0]  # numpy/voxelizer.py:275-276
+        else:
+            C_ = n_types  # max(types) + 1 over ALL atoms, numpy/voxelizer.py:278
+        c, t, r, in_kind, keep = self._prepare_inputs(coords, types, "types", radii)
+        if self.is_radii_type_channel_wise and r is not None and r.shape[0] < C_:
+            # channel-wise radii are indexed by type only; pad so the (C,) contract of the ABI holds
+            pad = C_ - r.shape[0]
+            r = torch.cat([r, r.new_ones(pad)]) if _is_torch(r) else np.concatenate([r, np.ones(pad, np.float32)])
+        xf = self._make_xform(center, random_translation, random_rotation)
+        buf, out_kind, ret, how = self._resolve_out(out_grid, (C_,))
+        rs = float(radii) if _np_isscalar(radii) else 0.0
+        _lib.check(self._lib.mvx_forward_types(
+            self._handle, self._ptr(c), self._ptr(t), self._ptr(r), rs, self._radii_type_code(), c.shape[0], int(C_),
+            C.cast(C.byref(xf), C.c_void_p), self._ptr(buf), in_kind, out_kind, self._stream()))
+        return self._finish_out(buf, ret, how)
+
+    def _check_args_types(self, coords, types, radii, out_grid=None):
+        V = coords.shape[0]
+        C_ = int(types.max()) + 1
+        D = H = W = self.dimension
+        assert tuple(types.shape) == (V,), f"types does not match dimension: {tuple(types.shape)} vs {(V,)}"
+        assert int(types.min()) >= 0, "types must be non-negative channel indices"
+        if self.is_radii_type_scalar:
+            assert _np_isscalar(radii), "the radii type of voxelizer is `scalar`, radii should be scalar"
+        elif self.is_radii_type_channel_wise:
+            assert not _np_isscalar(radii), f"the radii type of voxelizer is `channel-wise`, radii should be Array[{C_},]"
+            assert tuple(radii.shape) == (C_,), f"radii does not match dimension (number of channels,): {tuple(radii.shape)} vs {(C_,)}"
+        else:
+            assert not _np_isscalar(radii), f"the radii type of voxelizer is `atom-wise`, radii should be Array[{V},]"
+            assert tuple(radii.shape) == (V,), f"radii does not match dimension (number of atoms,): {tuple(radii.shape)} vs {(V,)}"
+        if out_grid is not None:
+            assert out_grid.shape[0] >= C_, f"Output channel is less than number of types: {out_grid.shape[0]} < {C_}"
+            assert tuple(out_grid.shape[1:]) == (D, H, W), f'Output grid dimension incorrect: {tuple(out_grid.shape)} vs {("*",D,H,W)}'
+        return C_
+
+    # ------------------------------------------------------------------------------------------
+    # SINGLE  (replaces numpy/voxelizer.py:370-477)
+    def forward_single(self, coords, center, radii, random_translation=0.0, random_rotation=False, out_grid=None):
+        """coords (V,3), center (3,) | None, radii scalar | (V,); out (1,D,H,W)."""
+        self._check_args_single(coords, radii, out_grid)
+        c, _, r, in_kind, keep = self._prepare_inputs(coords, None, None, radii)
+        xf = self._make_xform(center, random_translation, random_rotation)
+        buf, out_kind, ret, how = self._resolve_out(out_grid, (1,))
+        rs = float(radii) if _np_isscalar(radii) else 0.0
+        _lib.check(self._lib.mvx_forward_single(
+            self._handle, self._ptr(c), self._ptr(r), rs, self._radii_type_code(), c.shape[0],
+            C.cast(C.byref(xf), C.c_void_p), self._ptr(buf), in_kind, out_kind, self._stream()))
+        return self._finish_out(buf, ret, how)
+
+    def _check_args_single(self, coords, radii, out_grid=None):
+        V = coords.shape[0]
+        D = H = W = self.dimension
+        assert not self.is_radii_type_channel_wise, "Channel-Wise Radii Type is not supported"
+        if self.is_radii_type_scalar:
+            assert _np_isscalar(radii), "the radii type of voxelizer is `scalar`, radii should be scalar"
+        else:
+            assert not _np_isscalar(radii), f"the radii type of voxelizer is `atom-wise`, radii should be Array[{V},]"
+            assert tuple(radii.shape) == (V,), f"radii does not match dimension (number of atoms,): {tuple(radii.shape)} vs {(V,)}"
+        if out_grid is not None:
+            assert out_grid.shape[0] == 1, "Output channel should be 1"
+            assert tuple(out_grid.shape[1:]) == (D, H, W), f'Output grid dimension incorrect: {tuple(out_grid.shape)} vs {("*",D,H,W)}'
+
+    # ------------------------------------------------------------------------------------------
+    # BATCH (the loop of test/test_time_numpy.py:11-15 as one launch; molecules are independent)
+    def forward_batch(self, coords, offsets, centers, channels, radii, num_channels=None, out_grid=None,
+                      random_translation=0.0, random_rotation=False):
+        """Voxelize B molecules stored back to back.
+
+        coords (sumN,3) float64; offsets (B+1,) int64 (host); centers (B,3) | None;
+        channels: (sumN,C) float -> features, (sumN,) int -> types, None -> single;
+        radii: python float | (sumN,) | (C,) per this voxelizer's radii_type.
+        out_grid: (B,C,D,H,W) float32 (torch CUDA tensor on this device or numpy), fully overwritten.
+        A random transform, if requested, is drawn per molecule in molecule order.
+        """
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        B = offsets.shape[0] - 1
+        assert offsets[0] == 0 and offsets[-1] == coords.shape[0], "offsets must span coords"
+        if channels is None:
+            kind, C_ = None, 1
+        elif channels.ndim == 1:
+            kind = "types"
+            C_ = num_channels if num_channels is not None else (
+                radii.shape[0] if self.is_radii_type_channel_wise else int(channels.max()) + 1)
+        else:
+            kind, C_ = "features", channels.shape[1]
+        c, ch, r, in_kind, keep = self._prepare_inputs(coords, channels, kind, radii)
+        need_xf = centers is not None or random_rotation or (random_translation and random_translation > 0.0)
+        xf_ptr = C.c_void_p(0)
+        if need_xf:
+            xfs = (_lib.MvxXform * B)()
+            cen = None
+            if centers is not None:
+                cen = centers.detach().cpu().numpy() if _is_torch(centers) else np.asarray(centers)
+                cen = cen.reshape(B, 3)
+            for b in range(B):
+                xfs[b] = self._make_xform(None if cen is None else cen[b], random_translation, random_rotation)
+            xf_ptr = C.cast(xfs, C.c_void_p)
+        if out_grid is None:
+            out_grid = self.get_empty_grid(C_, batch_size=B)
+        assert tuple(out_grid.shape) == (B,) + self.grid_dimension(C_), (
+            f"Output grid dimension incorrect: {tuple(out_grid.shape)} vs {(B,) + self.grid_dimension(C_)}")
+        buf, out_kind, ret, how = self._resolve_out(out_grid, None)
+        rs = float(radii) if _np_isscalar(radii) else 0.0
+        off_ptr = C.c_void_p(offsets.ctypes.data)
+        rt = self._radii_type_code()
+        if kind == "features":
+            rc = self._lib.mvx_forward_features_batch(self._handle, self._ptr(c), self._ptr(ch), self._ptr(r), rs, rt,
+                                                      off_ptr, xf_ptr, B, int(C_), self._ptr(buf), in_kind, out_kind,
+                                                      self._stream())
+        elif kind == "types":
+            rc = self._lib.mvx_forward_types_batch(self._handle, self._ptr(c), self._ptr(ch), self._ptr(r), rs, rt,
+                                                   off_ptr, xf_ptr, B, int(C_), self._ptr(buf), in_kind, out_kind,
+                                                   self._stream())
+        else:
+            assert not self.is_radii_type_channel_wise, "Channel-Wise Radii Type is not supported"
+            rc = self._lib.mvx_forward_single_batch(self._handle, self._ptr(c), self._ptr(r), rs, rt, off_ptr, xf_ptr,
+                                                    B, self._ptr(buf), in_kind, out_kind, self._stream())
+        _lib.check(rc)
+        return self._finish_out(buf, ret, how)
+
+    # ------------------------------------------------------------------------------------------
+    # measurement hooks used by bench.py (HIP events around the voxelize kernel on the launch stream)
+    def set_profiling(self, enable: bool):
+        _lib.check(self._lib.mvx_set_profiling(self._handle, 1 if enable else 0))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float(0.0)
+        _lib.check(self._lib.mvx_last_kernel_ms(self._handle, C.byref(ms)))
+        return ms.value
+
+    @staticmethod
+    def do_random_transform(coords, center, random_translation, random_rotation):
+        from .transform import do_random_transform
+
+        return do_random_transform(coords, center, random_translation, random_rotation)
+
+
+def transform_on_device(coords, center, translation, quaternion):
+    """do_transform for a torch CUDA tensor (N,3): runs mvx_transform_coords on the tensor's device."""
+    lib = _lib.load()
+    dev = coords.device.index if coords.device.index is not None else torch.cuda.current_device()
+    vox = _transform_handles.get(dev)
+    if vox is None:
+        vox = _transform_handles[dev] = Voxelizer(0.5, 8, device=dev)
+    xf = _lib.MvxXform()
+    flags = 0
+    if quaternion is not None:
+        xf.quat[:] = [float(q) for q in quaternion]
+        flags |= _lib.MVX_XF_ROTATE
+        if center is not None:
+            cen = center.detach().cpu().numpy() if _is_torch(center) else np.asarray(center)
+            xf.center[:] = cen.reshape(3).astype(np.float64).tolist()
+            flags |= _lib.MVX_XF_CENTER | _lib.MVX_XF_RECENTER
+    if translation is not None:
+        tr = translation.detach().cpu().numpy() if _is_torch(translation) else np.asarray(translation)
+        xf.trans[:] = tr.reshape(3).astype(np.float32).tolist()
+        flags |= _lib.MVX_XF_TRANSLATE
+    xf.flags = flags
+    src = coords.to(torch.float64).contiguous()
+    out = torch.empty_like(src)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.mvx_transform_coords(vox._handle, C.c_void_p(src.data_ptr()), src.shape[0],
+                                        C.cast(C.byref(xf), C.c_void_p), C.c_void_p(out.data_ptr()),
+                                        _lib.MVX_DEVICE, _lib.MVX_DEVICE, stream))
+    return out
+
+
+_transform_handles: dict = {}

@@ -1,0 +1,309 @@
+"""Parity of the HIP path (through the Python operator API and the C ABI) with the reference.
+
+Compared against (a) the committed goldens produced by the imported reference numpy backend and
+(b) the CPU oracle on the same seeded inputs.
+Bar (BASELINE.json north_star): binary bit-exact; Gaussian <= 1e-5 abs. The tests use a tighter
+5e-6 for Gaussian; membership (which voxels are non-zero) must be identical in every case.
+"""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from tests import goldens
+
+pytestmark = pytest.mark.gpu
+
+GAUSS_TOL = 5e-6
+
+Z_SMALL, IDX_SMALL = goldens.load("small_cases.npz")
+Z_BIG, IDX_BIG = goldens.load("big_cases.npz")
+Z_API, IDX_API = goldens.load("api_cases.npz")
+
+
+@pytest.fixture(scope="module")
+def mv():
+    import molvoxel_amd
+
+    return molvoxel_amd
+
+
+def _make(mv, case_or_kw, **over):
+    kw = dict(case_or_kw)
+    kw.update(over)
+    extra = {}
+    if kw.get("blockdim") is not None:
+        extra["blockdim"] = kw["blockdim"]
+    if kw["density"] == "gaussian":
+        extra["sigma"] = kw["sigma"]
+    return mv.create_voxelizer(kw["resolution"], kw["dimension"], kw["radii_type"], kw["density"], "hip",
+                               output="numpy", **extra)
+
+
+def _compare(out, ref, exact):
+    assert out.shape == ref.shape and out.dtype == np.float32
+    assert np.array_equal(out != 0, ref != 0), f"membership differs in {(np.not_equal(out != 0, ref != 0)).sum()} voxels"
+    if exact:
+        assert np.array_equal(out, ref)
+    else:
+        assert np.abs(out - ref).max() <= GAUSS_TOL
+
+
+@pytest.mark.parametrize("case", IDX_SMALL, ids=[c["id"] for c in IDX_SMALL])
+def test_small_golden(mv, case):
+    coords, chan, radii = goldens.small_case_inputs(Z_SMALL, case)
+    ref = Z_SMALL[f"{case['id']}/out"]
+    v = _make(mv, case)
+    out = v.forward(coords, None, chan, radii)
+    _compare(out, ref, exact=(case["density"] == "binary" and case["mode"] != "features"))
+    if case["density"] == "binary" and case["mode"] == "features":
+        # binary features: sums of the same float32 feature values; only the summation order may differ
+        assert np.abs(out - ref).max() <= 1e-6
+
+
+def _workload(case):
+    from molvoxel_amd import workloads as W
+
+    name = case["workload"]
+    if name == "cfg1":
+        pc = np.load(goldens.GOLD + "/pointcloud_10gs.npz")
+        return W.cfg1(pc["ligand_xyz"], pc["ligand_feat5"])
+    if name == "cfg4":
+        return W.cfg4(batch=8)
+    return getattr(W, name)()
+
+
+@pytest.mark.parametrize("case", IDX_BIG, ids=[c["id"] for c in IDX_BIG])
+def test_baseline_configs_golden_and_oracle(mv, case):
+    """BASELINE.json configs at full size: golden sha/samples from the reference + full-array oracle compare."""
+    from oracle import c_oracle
+
+    wl = _workload(case)
+    i = case["molecule"]
+    _, mode, density = case["id"].split("_")[:3]
+    chan = None if mode == "single" else wl.channels[i]
+    v = mv.create_voxelizer(wl.resolution, wl.dimension, wl.radii_type, density, "hip", output="numpy",
+                            **({"sigma": wl.sigma} if density == "gaussian" else {}))
+    out = v.forward(wl.coords[i], wl.centers[i], chan, wl.radii[i])
+    assert list(out.shape) == case["shape"]
+    assert int(np.count_nonzero(out)) == case["nonzero"]
+    if case["exact"]:
+        assert hashlib.sha256(out.tobytes()).hexdigest() == case["sha256"]
+    idx, val = Z_BIG[f"{case['id']}/sample_idx"], Z_BIG[f"{case['id']}/sample_val"]
+    assert np.abs(out.reshape(-1)[idx] - val).max() <= (0 if case["exact"] else GAUSS_TOL)
+    sums = out.reshape(out.shape[0], -1).sum(axis=1, dtype=np.float64)
+    assert np.allclose(sums, Z_BIG[f"{case['id']}/chan_sums"], rtol=2e-6, atol=1e-3)
+    # full-array comparison with the CPU oracle (itself pinned to the reference by test_oracle_golden.py)
+    xyz = wl.coords[i] - wl.centers[i].reshape(1, 3)
+    ora = c_oracle.voxelize(xyz, chan, wl.radii[i], resolution=wl.resolution, dimension=wl.dimension,
+                            radii_type=wl.radii_type, density=density, sigma=wl.sigma, num_channels=out.shape[0])
+    _compare(out, ora, exact=case["exact"])
+
+
+def test_api_cases(mv):
+    """End-to-end calls recorded through the reference's public API (centring, seeded random transform,
+    out_grid reuse with an extra channel, radii_type / density_type switches)."""
+    z = Z_API
+    xyz, types, center = z["sys_xyz"], z["sys_types"], z["center"]
+    pc = np.load(goldens.GOLD + "/pointcloud_10gs.npz")
+    lig, lig_f = pc["ligand_xyz"], pc["ligand_feat5"]
+
+    v = mv.create_voxelizer(0.5, 32, library="hip", output="numpy")
+    g = v.get_empty_grid(10)
+    out = v.forward(xyz, center, types, 1.0, out_grid=g)
+    assert out is g  # in-place contract (reference test/test_run_numpy.py:46)
+    _compare(out, z["a0/out"], False)
+
+    np.random.seed(123)
+    out = v.forward(xyz, center, types, 1.0, random_translation=0.5, random_rotation=True)
+    _compare(out, z["a1/out"], False)
+
+    v.radii_type = "channel-wise"
+    _compare(v.forward(xyz, center, types, z["a2/r_chan"]), z["a2/out"], False)
+    v.radii_type = "atom-wise"
+    _compare(v.forward(xyz, center, types, z["a2/r_chan"][types]), z["a3/out"], False)
+    v.radii_type = "scalar"
+    v.density_type = "binary"
+    _compare(v.forward(xyz, center, types, 1.5), z["a4/out"], True)
+
+    v2 = mv.create_voxelizer(0.5, 32, library="hip", output="numpy")
+    _compare(v2.forward(lig, center, lig_f, 1.0), z["a5/out"], False)
+    _compare(v2.forward(lig, center, None, 1.0), z["a6/out"], False)
+    _compare(v2.forward(lig.astype(np.float32), None, lig_f, 1.0), z["a7/out"], False)
+
+
+def test_determinism_and_types_equals_onehot_features(mv):
+    """The reference's own assertions (test/test_time_numpy.py:65-69): repeated calls agree, and
+    forward_types equals forward_features on one-hot features, to 1e-5."""
+    from molvoxel_amd import workloads as W
+
+    wl = W.cfg3()
+    v = mv.create_voxelizer(0.5, 48, "scalar", "gaussian", "hip", output="numpy")
+    t = wl.channels[0]
+    a = v.forward(wl.coords[0], wl.centers[0], t, 1.0)
+    b = v.forward(wl.coords[0], wl.centers[0], t, 1.0)
+    assert np.array_equal(a, b)
+    onehot = np.eye(4, dtype=np.float32)[t]
+    c = v.forward(wl.coords[0], wl.centers[0], onehot, 1.0)
+    assert np.abs(a - c).max() < 1e-5
+
+
+def test_c_abi_direct_host_pointers(mv):
+    """Call the C ABI directly (no Python operator layer): mvx_create / mvx_forward_types / mvx_destroy."""
+    from molvoxel_amd import workloads as W
+    from molvoxel_amd.voxelizer.hip import _lib
+    from oracle import c_oracle
+
+    lib = _lib.load()
+    assert lib.mvx_version() == 100
+    wl = W.cfg3()
+    cfg = _lib.MvxConfig(0.5, 0.5, 48, 8, _lib.MVX_BINARY, 0)
+    h = _lib.Handle()
+    _lib.check(lib.mvx_create(C.byref(cfg), C.byref(h)))
+    xyz = np.ascontiguousarray(wl.coords[0])
+    types = np.ascontiguousarray(wl.channels[0], dtype=np.int32)
+    out = np.full((4, 48, 48, 48), np.nan, dtype=np.float32)
+    _lib.check(lib.mvx_forward_types(h, xyz.ctypes.data, types.ctypes.data, None, 1.0, _lib.MVX_RADII_SCALAR,
+                                     xyz.shape[0], 4, None, out.ctypes.data, _lib.MVX_HOST, _lib.MVX_HOST, None))
+    ref = c_oracle.voxelize(xyz, types, 1.0, dimension=48, density="binary", num_channels=4)
+    assert np.array_equal(out, ref)
+    # error path: channel-wise radii are rejected for forward_single with the reference's message
+    rc = lib.mvx_forward_single(h, xyz.ctypes.data, xyz.ctypes.data, 1.0, _lib.MVX_RADII_CHANNEL, xyz.shape[0], None,
+                                out.ctypes.data, _lib.MVX_HOST, _lib.MVX_HOST, None)
+    assert rc == -1 and b"Channel-Wise" in lib.mvx_last_error()
+    _lib.check(lib.mvx_destroy(h))
+
+
+def test_batch_matches_per_molecule_and_ragged_empty(mv):
+    """forward_batch (one launch) == per-molecule calls; ragged sizes incl. an empty molecule."""
+    from molvoxel_amd import workloads as W
+
+    wl = W.cfg4(batch=6)
+    coords = [c for c in wl.coords]
+    feats = [f for f in wl.channels]
+    coords[2] = coords[2][:0]  # empty molecule
+    feats[2] = feats[2][:0]
+    offsets = np.cumsum([0] + [c.shape[0] for c in coords])
+    v = mv.create_voxelizer(0.5, 64, "scalar", "gaussian", "hip", output="numpy")
+    out = v.forward_batch(np.concatenate(coords), offsets, None, np.concatenate(feats), 1.0)
+    assert out.shape == (6, 16, 64, 64, 64)
+    for b in range(6):
+        one = v.forward(coords[b], None, feats[b], 1.0) if coords[b].shape[0] else np.zeros_like(out[b])
+        assert np.array_equal(out[b], one)
+    assert not out[2].any()
+
+
+def test_torch_device_tensors_zero_copy(mv):
+    """torch CUDA tensors in and out (data_ptr hand-off on the current stream); same bits as the host path."""
+    import torch
+
+    from molvoxel_amd import workloads as W
+
+    wl = W.cfg2(n_atoms=500, channels=32)
+    vt = mv.create_voxelizer(0.5, 64, "scalar", "gaussian", "hip")
+    vn = mv.create_voxelizer(0.5, 64, "scalar", "gaussian", "hip", output="numpy")
+    coords = vt.asarray(wl.coords[0], "coords")
+    feats = vt.asarray(wl.channels[0], "features")
+    center = vt.asarray(wl.centers[0], "center")
+    assert coords.is_cuda and coords.dtype == torch.float64 and feats.dtype == torch.float32
+    grid = vt.get_empty_grid(32)
+    out = vt.forward(coords, center, feats, 1.0, out_grid=grid)
+    assert out is grid and out.is_cuda
+    host = vn.forward(wl.coords[0], wl.centers[0], wl.channels[0], 1.0)
+    assert np.array_equal(out.cpu().numpy(), host)
+
+
+def test_size_independent_properties_full_size(mv):
+    """cfg-2 size: linearity in the features, channel permutation, and Gaussian <= binary support."""
+    from molvoxel_amd import workloads as W
+
+    wl = W.cfg2()
+    xyz, f = wl.coords[0], wl.channels[0]
+    v = mv.create_voxelizer(0.5, 64, "scalar", "gaussian", "hip", output="numpy")
+    a = v.forward(xyz, None, f, 1.0)
+    # scaling by a power of two is exact in float32
+    assert np.array_equal(v.forward(xyz, None, f * np.float32(2.0), 1.0), a * np.float32(2.0))
+    perm = np.random.default_rng(0).permutation(32)
+    assert np.array_equal(v.forward(xyz, None, f[:, perm], 1.0), a[perm])
+    # each channel is independent of the others: C=32 result restricted to 4 channels == C=4 result
+    assert np.array_equal(v.forward(xyz, None, np.ascontiguousarray(f[:, :4]), 1.0), a[:4])
+    v.density_type = "binary"
+    s_bin = v.forward(xyz, None, None, 1.0)
+    v.density_type = "gaussian"
+    s_gau = v.forward(xyz, None, None, 1.0)
+    assert np.array_equal(s_bin != 0, s_gau != 0)
+    assert s_bin.sum() == float(np.count_nonzero(s_bin)) or s_bin.max() > 1  # integer counts
+    assert np.array_equal(s_bin, np.round(s_bin))
+
+
+def test_blockdim_modes(mv):
+    """blockdim emulation: default 8 reproduces the reference's block-cull artefact, blockdim=dimension removes it."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(9)
+    D = 32
+    W_ = 0.5 * (D - 1)
+    xyz = rng.uniform(-W_ / 2, W_ / 2, (500, 3))
+    for bd in (8, 32, 16, 5, 12):
+        v = mv.create_voxelizer(0.5, D, "scalar", "binary", "hip", output="numpy", blockdim=bd)
+        out = v.forward(xyz, None, None, 1.0)
+        ref = c_oracle.voxelize(xyz, None, 1.0, dimension=D, blockdim=bd, density="binary")
+        assert np.array_equal(out, ref), f"blockdim={bd}"
+    one = mv.create_voxelizer(0.5, D, "scalar", "binary", "hip", output="numpy", blockdim=D).forward(xyz, None, None, 1.0)
+    eight = mv.create_voxelizer(0.5, D, "scalar", "binary", "hip", output="numpy").forward(xyz, None, None, 1.0)
+    assert (one != eight).sum() > 0  # ~0.5 % of voxels differ
+
+
+def test_many_channels_and_odd_dimension(mv):
+    """C > 32 (several channel chunks) and a dimension that is not a multiple of 4 (scalar-store path)."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(3)
+    for D, C_ in ((30, 70), (17, 3), (64, 40)):
+        W_ = 0.5 * (D - 1)
+        xyz = rng.uniform(-W_ / 2 - 1, W_ / 2 + 1, (300, 3))
+        f = rng.random((300, C_)).astype(np.float32)
+        v = mv.create_voxelizer(0.5, D, "scalar", "gaussian", "hip", output="numpy")
+        out = v.forward(xyz, None, f, 1.25)
+        ref = c_oracle.voxelize(xyz, f, 1.25, dimension=D)
+        _compare(out, ref, False)
+
+
+def test_dense_cluster_exceeds_candidate_capacity(mv):
+    """Thousands of atoms inside one slab: exercises the multi-round scan and chunked LDS staging."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(4)
+    xyz = rng.normal(scale=0.8, size=(3000, 3))
+    t = rng.integers(0, 3, 3000)
+    v = mv.create_voxelizer(0.5, 24, "scalar", "binary", "hip", output="numpy")
+    out = v.forward(xyz, None, t, 1.0)
+    ref = c_oracle.voxelize(xyz, t, 1.0, dimension=24, density="binary", num_channels=3)
+    assert np.array_equal(out, ref)
+    f = rng.random((3000, 32)).astype(np.float32)
+    vg = mv.create_voxelizer(0.5, 24, "scalar", "gaussian", "hip", output="numpy")
+    outg = vg.forward(xyz, None, f, 1.0)
+    refg = c_oracle.voxelize(xyz, f, 1.0, dimension=24)
+    assert np.array_equal(outg != 0, refg != 0)
+    assert np.abs(outg - refg).max() <= 2e-4 * max(1.0, float(refg.max()) / 100)  # sums of ~1000 terms
+
+
+def test_transform_objects_on_device(mv):
+    """T / RandomTransform on torch CUDA tensors equal the seeded reference results (goldens)."""
+    import torch
+
+    z, idx = goldens.load("transform_cases.npz")
+    xyz, center = z["coords"], z["center"]
+    tx = torch.as_tensor(xyz, device="cuda")
+    rt_mod = __import__("molvoxel_amd.voxelizer.hip.transform", fromlist=["x"])
+    for case in idx:
+        np.random.seed(case["seed"])
+        if case["id"].startswith("t"):
+            out = rt_mod.do_random_transform(tx, center if case["use_center"] else None,
+                                             case["random_translation"], case["random_rotation"])
+            assert np.array_equal(np.random.rand(2), z[f"{case['id']}/next_rand"])
+        else:
+            T = mv.create_random_transform(case["random_translation"], case["random_rotation"], "hip").get_transform()
+            out = T(tx, center)
+        assert np.array_equal(out.cpu().numpy(), z[f"{case['id']}/out"]), case["id"]
