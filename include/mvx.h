@@ -153,10 +153,14 @@ int mvx_forward_single(mvx_handle *h, const double *coords, const float *radii, 
 int mvx_transform_coords(mvx_handle *h, const double *coords, int64_t N, const mvx_xform *xform, double *out,
                          int32_t in_kind, int32_t out_kind, void *stream);
 
-/* Timing of the last voxelize launch on this handle, measured with HIP events on the launch
- * stream around the dominant (voxelize) kernel only. Enabled by mvx_set_profiling(h, 1);
- * mvx_last_kernel_ms synchronises on the stop event. Used by bench.py for `roofline.achieved`. */
+/* Kernel timing, measured with HIP events recorded on the launch stream immediately before and
+ * after the dominant (voxelize) kernel of every call while profiling is enabled. Recording does not
+ * synchronise; up to MVX_PROFILE_RING launches are kept. mvx_profile_read synchronises on the last
+ * event, writes the per-launch durations (ms, oldest first) and resets the ring. bench.py uses it
+ * for `roofline.achieved`; mvx_last_kernel_ms is the single-launch convenience form. */
+#define MVX_PROFILE_RING 1024
 int mvx_set_profiling(mvx_handle *h, int32_t enable);
+int mvx_profile_read(mvx_handle *h, float *ms, int32_t capacity, int32_t *count);
 int mvx_last_kernel_ms(mvx_handle *h, float *ms);
 
 /* Device memory helpers for callers without a device allocator of their own (torch-less use;

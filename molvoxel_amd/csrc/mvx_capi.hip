@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 using namespace mvx;
 
@@ -56,11 +57,12 @@ struct mvx_handle {
     Geom g;
     float sigma32;
     int device;
-    DevBuf rec, bbox, meta, aux, in_coords, in_chan, in_radii, out_stage;
+    DevBuf rec, bbox, xlist, xcount, meta, aux, in_coords, in_chan, in_radii, out_stage;
     PinnedSlot slots[NSLOTS];
     int next_slot = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool profiling = false, timed = false;
+    std::vector<hipEvent_t> ev; // 2 * MVX_PROFILE_RING events, created on first use
+    int ev_count = 0;           // timed launches recorded since the last read
+    bool profiling = false;
     int force_nw = 0;
 };
 
@@ -284,7 +286,6 @@ int run(mvx_handle *h, const RunArgs &r) {
     // ---- voxelize ---------------------------------------------------------------------------------
     VoxArgs va;
     va.rec = pa.rec;
-    va.bbox = pa.bbox;
     va.offsets = d_off;
     va.features = (r.mode == MODE_FEATURES) ? reinterpret_cast<const float *>(d_chan) : nullptr;
     va.Tc = d_Tc;
@@ -295,9 +296,17 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.D = D;
     va.C = r.C;
     va.B = r.B;
+    // slab = 4 x 4 x (4*NW) voxels, NW waves. Keep z-runs whole 128-B lines: 8 sub-tiles (32 floats) per
+    // workgroup when the row length allows it, otherwise one workgroup per full row (<= 16 sub-tiles).
     const int nz4 = (D + 3) / 4;
-    int nzc = (nz4 + 15) / 16;
-    int NW = (nz4 + nzc - 1) / nzc;
+    int NW, nzc;
+    if (nz4 <= 8 || (nz4 <= 16 && nz4 % 8 != 0)) {
+        NW = nz4;
+        nzc = 1;
+    } else {
+        NW = 8;
+        nzc = (nz4 + 7) / 8;
+    }
     if (h->force_nw > 0 && h->force_nw <= 16) {
         NW = std::min(h->force_nw, nz4);
         nzc = (nz4 + NW - 1) / NW;
@@ -305,6 +314,13 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.nsx = nz4;
     va.nzc = nzc;
     va.NW = NW;
+    // x-slab binning (ordered lists per (molecule, x-slab))
+    if ((rc = ensure(h->xlist, n_alloc * (size_t)nz4 * sizeof(uint4)))) return rc;
+    if ((rc = ensure(h->xcount, (size_t)r.B * nz4 * sizeof(int)))) return rc;
+    HIP_TRY(launch_xbin(pa.bbox, d_off, r.B, nz4, reinterpret_cast<uint4 *>(h->xlist.p),
+                        reinterpret_cast<int *>(h->xcount.p), s));
+    va.xlist = reinterpret_cast<const uint4 *>(h->xlist.p);
+    va.xcount = reinterpret_cast<const int *>(h->xcount.p);
     va.ncc = (r.C + 31) / 32;
     va.mode = r.mode;
     va.vec_store = (D % 4 == 0) ? 1 : 0;
@@ -313,11 +329,12 @@ int run(mvx_handle *h, const RunArgs &r) {
     // a 4^3 sub-tile lies inside one reference block when 4 | blockdim (or there is a single block):
     // the block cull is then wave-uniform and already folded into the candidate ranges.
     const bool lane_range = !(g.nb == 1 || g.bd % 4 == 0);
-    if (h->profiling) HIP_TRY(hipEventRecord(h->ev0, s));
+    const bool timed = h->profiling && h->ev_count < MVX_PROFILE_RING;
+    if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count], s));
     HIP_TRY(launch_voxelize(va, ct, gauss, chanwise, lane_range, s));
-    if (h->profiling) {
-        HIP_TRY(hipEventRecord(h->ev1, s));
-        h->timed = true;
+    if (timed) {
+        HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count + 1], s));
+        ++h->ev_count;
     }
 
     HIP_TRY(hipEventRecord(slot->done, s));
@@ -383,10 +400,6 @@ int mvx_create(const mvx_config *cfg, mvx_handle **out) {
         delete h;
         return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
-    if ((e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
-        delete h;
-        return fail_hip(e, "hipEventCreate");
-    }
     *out = h;
     return MVX_OK;
 }
@@ -395,15 +408,14 @@ int mvx_destroy(mvx_handle *h) {
     if (!h) return MVX_OK;
     DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&h->rec, &h->bbox, &h->meta, &h->aux, &h->in_coords, &h->in_chan, &h->in_radii, &h->out_stage};
+    DevBuf *bufs[] = {&h->rec, &h->bbox, &h->xlist, &h->xcount, &h->meta, &h->aux, &h->in_coords, &h->in_chan, &h->in_radii, &h->out_stage};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (PinnedSlot &s : h->slots) {
         if (s.p) (void)hipHostFree(s.p);
         if (s.done) (void)hipEventDestroy(s.done);
     }
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
     return MVX_OK;
 }
@@ -510,17 +522,38 @@ int mvx_transform_coords(mvx_handle *h, const double *coords, int64_t N, const m
 
 int mvx_set_profiling(mvx_handle *h, int32_t enable) {
     if (!h) return fail(MVX_ERR_INVALID, "null handle");
+    DeviceGuard guard(h->device);
+    if (enable && h->ev.empty()) {
+        h->ev.reserve(2 * MVX_PROFILE_RING);
+        for (int i = 0; i < 2 * MVX_PROFILE_RING; ++i) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+    }
     h->profiling = enable != 0;
-    h->timed = false;
+    h->ev_count = 0;
+    return MVX_OK;
+}
+
+int mvx_profile_read(mvx_handle *h, float *ms, int32_t capacity, int32_t *count) {
+    if (!h || !count || (capacity > 0 && !ms)) return fail(MVX_ERR_INVALID, "null argument");
+    DeviceGuard guard(h->device);
+    const int n = std::min<int>(h->ev_count, capacity);
+    if (h->ev_count > 0) HIP_TRY(hipEventSynchronize(h->ev[2 * h->ev_count - 1]));
+    for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], h->ev[2 * i], h->ev[2 * i + 1]));
+    *count = n;
+    h->ev_count = 0;
     return MVX_OK;
 }
 
 int mvx_last_kernel_ms(mvx_handle *h, float *ms) {
     if (!h || !ms) return fail(MVX_ERR_INVALID, "null argument");
-    if (!h->timed) return fail(MVX_ERR_INVALID, "no timed launch (call mvx_set_profiling(h, 1) first)");
+    if (h->ev_count <= 0) return fail(MVX_ERR_INVALID, "no timed launch (call mvx_set_profiling(h, 1) first)");
     DeviceGuard guard(h->device);
-    HIP_TRY(hipEventSynchronize(h->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    const int i = h->ev_count - 1;
+    HIP_TRY(hipEventSynchronize(h->ev[2 * i + 1]));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev[2 * i], h->ev[2 * i + 1]));
     return MVX_OK;
 }
 

@@ -53,7 +53,8 @@ struct PrepArgs {
 
 struct VoxArgs {
     const AtomRec *rec;
-    const uint4 *bbox;
+    const uint4 *xlist;    // x-slab lists (xbin_kernel)
+    const int *xcount;     // their lengths, [B * nsx]
     const int64_t *offsets;
     const float *features; // (total, C) or null
     const double *Tc;      // channel-wise features: per-channel d2 thresholds
@@ -73,12 +74,12 @@ struct VoxArgs {
 hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax,
                            double *Tc, float *kc, hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
+hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, uint4 *xlist, int *xcount,
+                       hipStream_t s);
 hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf_dev, double *out, hipStream_t s);
 // ct: channels per thread (1, 4, 8, 16, 32); lane_range: per-lane index-range check needed
 hipError_t launch_voxelize(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
 hipError_t configure_kernels(); // raises the dynamic-LDS limit of every instantiation
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t *dcap, int32_t *union_bytes);
-
-constexpr int ICAP = 1024; // candidate index list capacity (>= max threads per workgroup)
 
 } // namespace mvx

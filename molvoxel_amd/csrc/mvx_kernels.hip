@@ -270,48 +270,93 @@ hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf
 }
 
 // ------------------------------------------------------------------------------------------------
+// x-slab binning: ordered list of the atoms whose admitted x-range touches each 4-voxel x-slab
+// ------------------------------------------------------------------------------------------------
+// One wave per (molecule, x-slab). Entries keep atom order (ballot + prefix compaction, no atomics,
+// so downstream float sums are reproducible). Entry = {atom index in molecule, yr, zr, 0}; list
+// (b, sx) lives at xlist[offsets[b] * nsx + sx * N_b] (capacity N_b), its length in xcount[b*nsx+sx].
+__global__ void __launch_bounds__(64) xbin_kernel(const uint4 *bbox, const int64_t *offsets, int nsx, uint4 *xlist,
+                                                  int *xcount) {
+    const int b = blockIdx.x / nsx, sx = blockIdx.x % nsx;
+    const int lane = threadIdx.x;
+    const int64_t a0 = offsets[b], a1 = offsets[b + 1];
+    const int x0 = 4 * sx;
+    uint4 *dst = xlist + a0 * nsx + (int64_t)sx * (a1 - a0);
+    int count = 0;
+    for (int64_t base = a0; base < a1; base += 64) {
+        const int64_t a = base + lane;
+        bool m = false;
+        uint4 bb = make_uint4(0, 0, 0, 0);
+        if (a < a1) {
+            bb = bbox[a];
+            m = ((int)(bb.x & 0xffff) <= x0 + 3) && ((int)(bb.x >> 16) >= x0);
+        }
+        const unsigned long long mask = __ballot(m);
+        if (m) {
+            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            dst[count + below] = make_uint4((unsigned)(a - a0), bb.y, bb.z, 0u);
+        }
+        count += __popcll(mask);
+    }
+    if (lane == 0) xcount[blockIdx.x] = count;
+}
+
+hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, uint4 *xlist, int *xcount,
+                       hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(64), 0, s, bbox, offsets, nsx, xlist, xcount);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // voxelize
 // ------------------------------------------------------------------------------------------------
-// LDS map (dynamic, 16-B aligned base):
-//   [0, 4*ICAP)            int   list[ICAP]      candidate atom indices of the slab, atom order
-//   [LDS_WCNT, +128)       int   wcnt[2][16]     per-wave match counts (double-buffered)
-//   [LDS_UNION, ...)       union {
-//        candidates:  uint32 zr[dcap] | records: dcap x (64 + 4*CT) bytes (AtomRec image + CT feature floats)
-//        out tile:    (CT*16) rows x RS floats,  RS = 4*NW + pad,  row = (c, x, y), pad keeps ds_write_b32
-//                     conflict-free: (RS/4) odd  }
-constexpr int LDS_WCNT = 4 * ICAP;
-constexpr int LDS_UNION = LDS_WCNT + 128;
-
+// LDS map (dynamic, 16-B aligned base), LCAP = 64 * NW (one scan step can add at most one entry per thread):
+//   [0, 4*LCAP)              int      list[LCAP]   candidate atom indices of the slab, atom order
+//   [4*LCAP, 8*LCAP)         uint32   zr[LCAP]     their admitted z ranges (per-wave sub-tile filter)
+//   [8*LCAP, +128)           int      wcnt[2][16]  per-wave match counts (double-buffered)
+//   [8*LCAP + 128, ...)      union {
+//        candidates:  dcap x STRIDE bytes: 48-B AtomRec head (px,py,pz,T,k,type,xr,yr) + CT feature floats
+//        out tile:    (CR*16) rows x RS floats, CR = min(CT, 16) channels per write-out round,
+//                     RS = 4*NW + pad, row = (c, x, y); pad keeps ds_write_b32 conflict-free ((RS/4) odd) }
 __host__ __device__ __forceinline__ int row_stride_floats(int NW) { return 4 * NW + ((NW & 1) ? 8 : 4); }
+__host__ __device__ __forceinline__ int cand_stride_bytes(int ct) { return 48 + (ct < 4 ? 16 : 4 * ct); }
 
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t *dcap, int32_t *union_bytes) {
-    const int stride = 64 + (ct < 4 ? 16 : 4 * ct);
-    const size_t tile = (size_t)ct * 16 * row_stride_floats(NW) * 4;
+    const int stride = cand_stride_bytes(ct);
+    const int cr = ct < 16 ? ct : 16;
+    const int lcap = 64 * NW;
+    const size_t tile = (size_t)cr * 16 * row_stride_floats(NW) * 4;
     size_t un = tile;
-    const size_t min_cand = (size_t)64 * (stride + 4) + 16;
+    const size_t min_cand = (size_t)96 * stride;
     if (un < min_cand) un = min_cand;
-    int cap = (int)((un - 16) / (stride + 4));
-    if (cap > ICAP) cap = ICAP;
-    cap &= ~3; // keeps the record base 16-B aligned
+    int cap = (int)(un / stride);
+    if (cap > lcap) cap = lcap;
     *dcap = cap;
     *union_bytes = (int32_t)un;
-    return (size_t)LDS_UNION + un;
+    return (size_t)8 * lcap + 128 + un;
 }
 
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
 __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *list = reinterpret_cast<int *>(smem);
-    int *wcnt = reinterpret_cast<int *>(smem + LDS_WCNT);
-    char *un = smem + LDS_UNION;
+    constexpr int STRIDE = 48 + (CT < 4 ? 16 : 4 * CT); // bytes, multiple of 16
+    constexpr int WT = 12 + CT;                          // words staged per candidate
+    constexpr int CR = CT < 16 ? CT : 16;                // channels per write-out round
+    constexpr int NROUND = CT / CR;
 
-    constexpr int STRIDE = 64 + (CT < 4 ? 16 : 4 * CT); // multiple of 16 B
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = A.NW;
     const int nthreads = NW * 64;
+    const int LCAP = nthreads;
     const int D = A.D;
+
+    int *list = reinterpret_cast<int *>(smem);
+    unsigned *zr_l = reinterpret_cast<unsigned *>(smem + 4 * LCAP);
+    int *wcnt = reinterpret_cast<int *>(smem + 8 * LCAP);
+    char *un = smem + 8 * LCAP + 128;
 
     // ---- block -> (molecule, channel chunk, slab) -------------------------------------------------
     int bid = blockIdx.x;
@@ -327,7 +372,10 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
 
     const int x0 = 4 * sx, y0 = 4 * sy, z0 = zc * 4 * NW;
     const int zhi_slab = z0 + 4 * NW - 1;
-    const int64_t a0 = A.offsets[b], a1 = A.offsets[b + 1];
+    const int64_t a0 = A.offsets[b];
+    const int nmol = (int)(A.offsets[b + 1] - a0);
+    const uint4 *xl = A.xlist + a0 * A.nsx + (int64_t)sx * nmol;
+    const int nx = A.xcount[b * A.nsx + sx];
 
     // ---- this lane's voxel ---------------------------------------------------------------------
     const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
@@ -342,34 +390,43 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
     for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
 
     bool any_candidate = false;
-    int64_t cursor = a0;
+    int cursor = 0;
     int phase = 0;
-    while (cursor < a1) {
-        // ---- 1. ordered scan of the molecule's atom ranges against the slab box -----------------
+    while (cursor < nx) {
+        // ---- 1. ordered compaction of the x-slab list against this slab's y/z box ----------------
         int nlist = 0;
-        while (cursor < a1 && nlist + nthreads <= ICAP) {
-            const int64_t a = cursor + tid;
+        while (cursor < nx && nlist + nthreads <= LCAP) {
+            const int i = cursor + tid;
             bool m = false;
-            if (a < a1) {
-                const uint4 bb = A.bbox[a];
-                const int xl = bb.x & 0xffff, xh = bb.x >> 16, yl = bb.y & 0xffff, yh = bb.y >> 16;
-                const int zl = bb.z & 0xffff, zh = bb.z >> 16;
-                m = (xl <= x0 + 3) && (xh >= x0) && (yl <= y0 + 3) && (yh >= y0) && (zl <= zhi_slab) && (zh >= z0);
+            uint4 e = make_uint4(0, 0, 0, 0);
+            if (i < nx) {
+                e = xl[i];
+                m = ((int)(e.y & 0xffff) <= y0 + 3) && ((int)(e.y >> 16) >= y0) && ((int)(e.z & 0xffff) <= zhi_slab) &&
+                    ((int)(e.z >> 16) >= z0);
             }
             const unsigned long long mask = __ballot(m);
             int *wc = wcnt + (phase & 1) * 16;
             if (lane == 0) wc[wave] = __popcll(mask);
             __syncthreads();
             int pre = 0, tot = 0;
-            for (int w = 0; w < NW; ++w) {
-                const int c = wc[w];
-                pre += (w < wave) ? c : 0;
-                tot += c;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                const int4 c4 = *reinterpret_cast<const int4 *>(wc + 4 * w4);
+                const int cs[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int w = 4 * w4 + k;
+                    const int c = (w < NW) ? cs[k] : 0;
+                    tot += c;
+                    pre += (w < wave) ? c : 0;
+                }
             }
             if (m) {
                 const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                list[nlist + pre + below] = (int)(a - a0);
+                const int pos = nlist + pre + below;
+                list[pos] = (int)e.x;
+                zr_l[pos] = e.z;
             }
             nlist += tot;
             cursor += nthreads;
@@ -379,29 +436,39 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
         if (nlist == 0) continue;
         any_candidate = true;
 
-        // ---- 2./3. stage candidates in chunks of dcap, accumulate ------------------------------
+        // ---- 2./3. stage candidates in chunks of dcap (flat, coalesced gather), accumulate ------
         for (int c0 = 0; c0 < nlist; c0 += A.dcap) {
             const int n = (nlist - c0) < A.dcap ? (nlist - c0) : A.dcap;
-            unsigned *zr_l = reinterpret_cast<unsigned *>(un);
-            char *cand = un + (((size_t)A.dcap * 4 + 15) & ~(size_t)15);
-            for (int j = wave; j < n; j += NW) {
-                const int64_t a = a0 + list[c0 + j];
-                const unsigned *src = reinterpret_cast<const unsigned *>(A.rec + a);
-                unsigned *dst = reinterpret_cast<unsigned *>(cand + (size_t)j * STRIDE);
-                if (lane < 16) {
-                    const unsigned v = src[lane];
-                    dst[lane] = v;
-                    if (lane == 12) zr_l[j] = v; // AtomRec::zr
-                } else if (lane < 16 + CT) {
-                    const int c = lane - 16;
-                    float f = 0.0f;
-                    if (cbase + c < A.C) {
-                        if (A.mode == MODE_FEATURES) f = A.features[a * A.C + cbase + c];
-                        else if (A.mode == MODE_TYPES) f = (A.rec[a].type == cbase + c) ? 1.0f : 0.0f;
-                        else f = 1.0f;
+            const int nwords = n * WT;
+            for (int i0 = tid; i0 < nwords; i0 += 4 * nthreads) {
+                unsigned v[4];
+                int dsti[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * nthreads;
+                    v[u] = 0u;
+                    dsti[u] = -1;
+                    if (i < nwords) {
+                        const int j = i / WT, w = i - j * WT;
+                        const int64_t a = a0 + list[c0 + j];
+                        dsti[u] = j * (STRIDE / 4) + w;
+                        if (w < 12) {
+                            v[u] = reinterpret_cast<const unsigned *>(A.rec + a)[w];
+                        } else {
+                            const int c = w - 12;
+                            float f = 0.0f;
+                            if (cbase + c < A.C) {
+                                if (A.mode == MODE_FEATURES) f = A.features[a * A.C + cbase + c];
+                                else if (A.mode == MODE_TYPES) f = (A.rec[a].type == cbase + c) ? 1.0f : 0.0f;
+                                else f = 1.0f;
+                            }
+                            v[u] = __float_as_uint(f);
+                        }
                     }
-                    reinterpret_cast<float *>(dst)[lane] = f;
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (dsti[u] >= 0) reinterpret_cast<unsigned *>(un)[dsti[u]] = v[u];
             }
             __syncthreads();
 
@@ -409,14 +476,14 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
                 const int j = jb + lane;
                 bool ok = false;
                 if (j < n) {
-                    const unsigned zr = zr_l[j];
+                    const unsigned zr = zr_l[c0 + j];
                     ok = ((int)(zr & 0xffff) <= zhi_w) && ((int)(zr >> 16) >= zlo_w);
                 }
                 unsigned long long mask = __ballot(ok);
                 while (mask) {
                     const int jj = jb + __builtin_ctzll(mask);
                     mask &= mask - 1;
-                    const char *r = cand + (size_t)jj * STRIDE;
+                    const char *r = un + (size_t)jj * STRIDE;
                     const double2 Pxy = *reinterpret_cast<const double2 *>(r);      // px, py
                     const double2 PzT = *reinterpret_cast<const double2 *>(r + 16); // pz, T
                     const double dx = Pxy.x - gx, dy = Pxy.y - gy, dz = PzT.x - gz;
@@ -426,11 +493,11 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
                         const uint4 q = *reinterpret_cast<const uint4 *>(r + 32); // k, type, xr, yr
                         hit = hit && (ix >= (int)(q.z & 0xffff)) && (ix <= (int)(q.z >> 16)) &&
                               (iy >= (int)(q.w & 0xffff)) && (iy <= (int)(q.w >> 16));
-                        const unsigned zr = *reinterpret_cast<const unsigned *>(r + 48);
+                        const unsigned zr = zr_l[c0 + jj];
                         hit = hit && (iz >= (int)(zr & 0xffff)) && (iz <= (int)(zr >> 16));
                     }
                     if (__ballot(hit) == 0ull) continue;
-                    const float *f = reinterpret_cast<const float *>(r + 64);
+                    const float *f = reinterpret_cast<const float *>(r + 48);
                     const float d2f = (float)d2;
                     if (!CHANWISE) {
                         float val = 0.0f;
@@ -464,49 +531,58 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
 
     // ---- 4. write-out ----------------------------------------------------------------------------
     const int RS = row_stride_floats(NW);
-    const size_t D2 = (size_t)D * D;
-    const int q = tid % NW;         // float4 slot inside a row
-    const int rfirst = tid / NW;    // first row of this thread; rows advance by 64 per pass
+    const size_t D2 = (size_t)D * D, D3 = D2 * D;
+    const int q = tid % NW;      // float4 slot inside a row
+    const int rfirst = tid / NW; // 0..63: row of this thread in pass 0; rows advance by 64 (= 4 channels) per pass
     const int zq = z0 + 4 * q;
-    const int nrows = CT * 16;
-    float *obase = A.out + ((size_t)b * A.C + cbase) * D2 * D;
+    const int sxx = (rfirst >> 2) & 3, syy = rfirst & 3, cfirst = rfirst >> 4;
+    const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
+    float *dst0 = A.out + ((size_t)b * A.C + cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
     if (!any_candidate) {
         // empty slab: pure zero fill with the same addressing (no LDS round trip)
-        for (int R = rfirst; R < nrows; R += 64) {
-            const int c = R >> 4, x = (R >> 2) & 3, y = R & 3;
-            if (cbase + c >= A.C || x0 + x >= D || y0 + y >= D || zq >= D) continue;
-            float *dst = obase + (size_t)c * D2 * D + (size_t)(x0 + x) * D2 + (size_t)(y0 + y) * D + zq;
-            if (A.vec_store) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                for (int e = 0; e < 4; ++e)
-                    if (zq + e < D) dst[e] = 0.0f;
+        if (vox_ok) {
+#pragma unroll 4
+            for (int c = cfirst; c < CT; c += 4) {
+                if (cbase + c >= A.C) break;
+                float *dst = dst0 + (size_t)(c - cfirst) * D3;
+                if (A.vec_store) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (zq + e < D) dst[e] = 0.0f;
+                }
             }
         }
         return;
     }
     float *tile = reinterpret_cast<float *>(un);
-    {
-        const int col = 4 * wave + lz;
-        const int rxy = lx * 4 + ly;
+    const int col = 4 * wave + lz;
+    const int rxy = lx * 4 + ly;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const float v = (c & 1) ? acc[c / 2].y : acc[c / 2].x;
+    for (int rd = 0; rd < NROUND; ++rd) {
+        if (rd > 0) __syncthreads(); // previous round fully read
+#pragma unroll
+        for (int c = 0; c < CR; ++c) {
+            const int cg = rd * CR + c;
+            const float v = (cg & 1) ? acc[cg / 2].y : acc[cg / 2].x;
             tile[(c * 16 + rxy) * RS + col] = v;
         }
-    }
-    __syncthreads();
-    for (int R = rfirst; R < nrows; R += 64) {
-        const int c = R >> 4, x = (R >> 2) & 3, y = R & 3;
-        if (cbase + c >= A.C || x0 + x >= D || y0 + y >= D || zq >= D) continue;
-        const float4 v = *reinterpret_cast<const float4 *>(tile + R * RS + 4 * q);
-        float *dst = obase + (size_t)c * D2 * D + (size_t)(x0 + x) * D2 + (size_t)(y0 + y) * D + zq;
-        if (A.vec_store) {
-            *reinterpret_cast<float4 *>(dst) = v;
-        } else {
-            const float e4[4] = {v.x, v.y, v.z, v.w};
-            for (int e = 0; e < 4; ++e)
-                if (zq + e < D) dst[e] = e4[e];
+        __syncthreads();
+        if (vox_ok) {
+#pragma unroll
+            for (int p = 0; p < (CR + 3) / 4; ++p) {
+                const int c = cfirst + 4 * p; // channel inside the round
+                if (c >= CR || cbase + rd * CR + c >= A.C) break;
+                const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 64 * p) * RS + 4 * q);
+                float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
+                if (A.vec_store) {
+                    *reinterpret_cast<float4 *>(dst) = v;
+                } else {
+                    const float e4[4] = {v.x, v.y, v.z, v.w};
+                    for (int e = 0; e < 4; ++e)
+                        if (zq + e < D) dst[e] = e4[e];
+                }
+            }
         }
     }
 }

@@ -57,6 +57,7 @@ SIGNATURES = {
     "mvx_forward_single": (C.c_int, [Handle, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _i32, _i32, _vp]),
     "mvx_transform_coords": (C.c_int, [Handle, _vp, _i64, _vp, _vp, _i32, _i32, _vp]),
     "mvx_set_profiling": (C.c_int, [Handle, _i32]),
+    "mvx_profile_read": (C.c_int, [Handle, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]),
     "mvx_last_kernel_ms": (C.c_int, [Handle, C.POINTER(C.c_float)]),
     "mvx_debug_read_records": (C.c_int, [Handle, _vp, _i64, _vp]),
     "mvx_alloc": (C.c_int, [Handle, _i64, C.POINTER(C.c_void_p)]),

@@ -418,6 +418,13 @@ class Voxelizer(BaseVoxelizer):
     def set_profiling(self, enable: bool):
         _lib.check(self._lib.mvx_set_profiling(self._handle, 1 if enable else 0))
 
+    def read_kernel_times_ms(self):
+        """Durations (ms) of the voxelize kernel for every launch since profiling was enabled / last read."""
+        buf = (C.c_float * 1024)()
+        n = C.c_int32(0)
+        _lib.check(self._lib.mvx_profile_read(self._handle, buf, 1024, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float(0.0)
         _lib.check(self._lib.mvx_last_kernel_ms(self._handle, C.byref(ms)))
