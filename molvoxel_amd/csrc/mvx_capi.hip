@@ -64,6 +64,8 @@ struct mvx_handle {
     int ev_count = 0;           // timed launches recorded since the last read
     bool profiling = false;
     int force_nw = 0;
+    int ablate = 0;
+    int xcd_remap = 1;
 };
 
 namespace {
@@ -291,11 +293,11 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.Tc = d_Tc;
     va.kc = d_kc;
     va.out = d_out;
-    va.res = g.res;
-    va.half = g.half;
-    va.D = D;
-    va.C = r.C;
-    va.B = r.B;
+    va.p.res = g.res;
+    va.p.half = g.half;
+    va.p.D = D;
+    va.p.C = r.C;
+    va.p.B = r.B;
     // slab = 4 x 4 x (4*NW) voxels, NW waves. Keep z-runs whole 128-B lines: 8 sub-tiles (32 floats) per
     // workgroup when the row length allows it, otherwise one workgroup per full row (<= 16 sub-tiles).
     const int nz4 = (D + 3) / 4;
@@ -311,21 +313,26 @@ int run(mvx_handle *h, const RunArgs &r) {
         NW = std::min(h->force_nw, nz4);
         nzc = (nz4 + NW - 1) / NW;
     }
-    va.nsx = nz4;
-    va.nzc = nzc;
-    va.NW = NW;
-    // x-slab binning (ordered lists per (molecule, x-slab))
-    if ((rc = ensure(h->xlist, n_alloc * (size_t)nz4 * sizeof(uint4)))) return rc;
+    va.p.nsx = nz4;
+    va.p.nzc = nzc;
+    va.p.NW = NW;
+    // x-slab binning (ordered lists per (molecule, x-slab), fixed-stride regions)
+    int64_t nmax = 1;
+    for (int b = 0; b < r.B; ++b) nmax = std::max<int64_t>(nmax, r.offsets[b + 1] - r.offsets[b]);
+    if ((rc = ensure(h->xlist, (size_t)r.B * nz4 * (size_t)nmax * sizeof(uint4)))) return rc;
     if ((rc = ensure(h->xcount, (size_t)r.B * nz4 * sizeof(int)))) return rc;
-    HIP_TRY(launch_xbin(pa.bbox, d_off, r.B, nz4, reinterpret_cast<uint4 *>(h->xlist.p),
+    HIP_TRY(launch_xbin(pa.bbox, d_off, r.B, nz4, (int32_t)nmax, reinterpret_cast<uint4 *>(h->xlist.p),
                         reinterpret_cast<int *>(h->xcount.p), s));
+    va.p.xstride = (int32_t)nmax;
     va.xlist = reinterpret_cast<const uint4 *>(h->xlist.p);
     va.xcount = reinterpret_cast<const int *>(h->xcount.p);
-    va.ncc = (r.C + 31) / 32;
-    va.mode = r.mode;
-    va.vec_store = (D % 4 == 0) ? 1 : 0;
+    va.p.ncc = (r.C + 31) / 32;
+    va.p.mode = r.mode;
+    va.p.vec_store = (D % 4 == 0) ? 1 : 0;
+    va.p.ablate = h->ablate;
+    va.p.xcd_remap = (h->xcd_remap && nzc > 1) ? 1 : 0;
     const int ct = pick_ct(std::min(r.C, 32));
-    (void)voxelize_lds_bytes(ct, NW, &va.dcap, &va.lds_union_bytes);
+    (void)voxelize_lds_bytes(ct, NW, &va.p.dcap);
     // a 4^3 sub-tile lies inside one reference block when 4 | blockdim (or there is a single block):
     // the block cull is then wave-uniform and already folded into the candidate ranges.
     const bool lane_range = !(g.nb == 1 || g.bd % 4 == 0);
@@ -391,6 +398,8 @@ int mvx_create(const mvx_config *cfg, mvx_handle **out) {
     h->device = cfg->device;
     make_geom(h);
     if (const char *env = std::getenv("MVX_NW")) h->force_nw = std::atoi(env);
+    if (const char *env = std::getenv("MVX_ABLATE")) h->ablate = std::atoi(env);
+    if (const char *env = std::getenv("MVX_XCD_REMAP")) h->xcd_remap = std::atoi(env);
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) {
         delete h;

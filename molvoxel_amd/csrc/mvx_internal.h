@@ -51,6 +51,19 @@ struct PrepArgs {
     uint4 *bbox; // {xr, yr, zr, 0} copy of the ranges, SoA for the slab scan
 };
 
+struct VoxParams { // by-value kernel parameters (scalars only: pointers are separate __restrict__ arguments)
+    double res, half;
+    int32_t D, C, B;
+    int32_t nsx, nzc, ncc; // slabs per x/y axis, z chunks, channel chunks
+    int32_t NW;            // waves per workgroup = 4^3 sub-tiles per slab
+    int32_t mode;
+    int32_t vec_store;     // D % 4 == 0 and out 16-B aligned
+    int32_t xcd_remap;     // 1: z-chunks of a column share an XCD (MVX_XCD_REMAP=0 disables)
+    int32_t xstride;       // entries per (molecule, x-slab) list region = largest molecule of the batch
+    int32_t dcap;          // candidates staged per round
+    int32_t ablate;        // timing experiments only (MVX_ABLATE): 1 = skip the candidate walk, 2 = treat every slab as empty
+};
+
 struct VoxArgs {
     const AtomRec *rec;
     const uint4 *xlist;    // x-slab lists (xbin_kernel)
@@ -60,26 +73,19 @@ struct VoxArgs {
     const double *Tc;      // channel-wise features: per-channel d2 thresholds
     const float *kc;       //                        per-channel gaussian coefficients
     float *out;            // (B, C, D, D, D)
-    double res, half;
-    int32_t D, C, B;
-    int32_t nsx, nzc, ncc; // slabs per x/y axis, z chunks, channel chunks
-    int32_t NW;            // waves per workgroup = 4^3 sub-tiles per slab
-    int32_t mode;
-    int32_t vec_store;     // D % 4 == 0 and out 16-B aligned
-    int32_t dcap;          // candidate staging capacity (records)
-    int32_t lds_union_bytes;
+    VoxParams p;
 };
 
 // launchers (host side, mvx_kernels.hip)
 hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax,
                            double *Tc, float *kc, hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
-hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, uint4 *xlist, int *xcount,
-                       hipStream_t s);
+hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, int32_t xstride, uint4 *xlist,
+                       int *xcount, hipStream_t s);
 hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf_dev, double *out, hipStream_t s);
 // ct: channels per thread (1, 4, 8, 16, 32); lane_range: per-lane index-range check needed
 hipError_t launch_voxelize(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
 hipError_t configure_kernels(); // raises the dynamic-LDS limit of every instantiation
-size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t *dcap, int32_t *union_bytes);
+size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t *dcap);
 
 } // namespace mvx

@@ -30,6 +30,7 @@
 #include "mvx_internal.h"
 
 #include <math.h>
+#include <stdio.h>
 
 // cdist-order arithmetic must not be fused, whatever flags the TU is built with.
 #pragma clang fp contract(off)
@@ -212,11 +213,13 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
 
     uint32_t rng[3] = {EMPTY_RANGE, EMPTY_RANGE, EMPTY_RANGE};
     if (keep) {
+        // Voxels that can pass |p - g_i| <= r are i in [ceil((p - r - g0)/res), floor((p + r - g0)/res)]; the
+        // radius is widened by 1e-6 relative (fp64 rounding of this estimate is ~1e-15) so the window is a
+        // superset of the membership set; membership itself is decided per voxel with the exact threshold.
         const double rr = (double)rwin * 1.000001 + 1e-9;
         for (int i = 0; i < 3; ++i) {
-            // conservative window of voxels that can be within the radius (membership is decided per voxel)
-            double flo = floor((p[i] - rr + g.half) / g.res) - 1.0;
-            double fhi = ceil((p[i] + rr + g.half) / g.res) + 1.0;
+            double flo = ceil((p[i] - rr + g.half) / g.res);
+            double fhi = floor((p[i] + rr + g.half) / g.res);
             flo = flo < 0.0 ? 0.0 : flo;
             fhi = fhi > (double)(g.D - 1) ? (double)(g.D - 1) : fhi;
             if (!(flo <= fhi)) {
@@ -274,14 +277,15 @@ hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf
 // ------------------------------------------------------------------------------------------------
 // One wave per (molecule, x-slab). Entries keep atom order (ballot + prefix compaction, no atomics,
 // so downstream float sums are reproducible). Entry = {atom index in molecule, yr, zr, 0}; list
-// (b, sx) lives at xlist[offsets[b] * nsx + sx * N_b] (capacity N_b), its length in xcount[b*nsx+sx].
-__global__ void __launch_bounds__(64) xbin_kernel(const uint4 *bbox, const int64_t *offsets, int nsx, uint4 *xlist,
-                                                  int *xcount) {
+// (b, sx) lives at xlist[(b*nsx + sx) * xstride] (xstride = largest molecule of the batch), its length in
+// xcount[b*nsx+sx].
+__global__ void __launch_bounds__(64) xbin_kernel(const uint4 *bbox, const int64_t *offsets, int nsx, int xstride,
+                                                  uint4 *xlist, int *xcount) {
     const int b = blockIdx.x / nsx, sx = blockIdx.x % nsx;
     const int lane = threadIdx.x;
     const int64_t a0 = offsets[b], a1 = offsets[b + 1];
     const int x0 = 4 * sx;
-    uint4 *dst = xlist + a0 * nsx + (int64_t)sx * (a1 - a0);
+    uint4 *dst = xlist + (size_t)blockIdx.x * (size_t)xstride; // fixed stride: addressable from blockIdx alone
     int count = 0;
     for (int64_t base = a0; base < a1; base += 64) {
         const int64_t a = base + lane;
@@ -301,88 +305,111 @@ __global__ void __launch_bounds__(64) xbin_kernel(const uint4 *bbox, const int64
     if (lane == 0) xcount[blockIdx.x] = count;
 }
 
-hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, uint4 *xlist, int *xcount,
-                       hipStream_t s) {
+hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, int32_t xstride, uint4 *xlist,
+                       int *xcount, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(64), 0, s, bbox, offsets, nsx, xlist, xcount);
+    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(64), 0, s, bbox, offsets, nsx, xstride, xlist,
+                       xcount);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
 // voxelize
 // ------------------------------------------------------------------------------------------------
-// LDS map (dynamic, 16-B aligned base), LCAP = 64 * NW (one scan step can add at most one entry per thread):
-//   [0, 4*LCAP)              int      list[LCAP]   candidate atom indices of the slab, atom order
-//   [4*LCAP, 8*LCAP)         uint32   zr[LCAP]     their admitted z ranges (per-wave sub-tile filter)
-//   [8*LCAP, +128)           int      wcnt[2][16]  per-wave match counts (double-buffered)
-//   [8*LCAP + 128, ...)      union {
-//        candidates:  dcap x STRIDE bytes: 48-B AtomRec head (px,py,pz,T,k,type,xr,yr) + CT feature floats
-//        out tile:    (CR*16) rows x RS floats, CR = min(CT, 16) channels per write-out round,
-//                     RS = 4*NW + pad, row = (c, x, y); pad keeps ds_write_b32 conflict-free ((RS/4) odd) }
+// One workgroup = one slab of 4 x 4 x (4*NW) voxels; one wave = one 4^3 sub-tile; one lane = one voxel with
+// CT channel accumulators in registers.
+//   1. scan: every thread loads one entry of the slab's x-list (address known from blockIdx alone, so the load
+//      is in flight while the list length is still being fetched) and tests its y/z ranges against the slab;
+//      matches are compacted in atom order (ballot + cross-wave prefix, one barrier) into an LDS list;
+//   2. stage: wave w copies candidates w, w+NW, ... (64-B record + CT feature floats, one coalesced load each,
+//      up to 8 in flight) into LDS; one barrier;
+//   3. walk: each wave picks the candidates whose z range touches its sub-tile (lane-parallel filter + ballot)
+//      and processes them: broadcast LDS reads, fp64 d2 in cdist order, compare with T, exp2, packed FMAs;
+//   4. write-out: accumulators -> LDS tile (CR = min(CT,16) channels per round) -> 16-B/lane stores in
+//      whole-row runs. Empty slabs skip the LDS round trip.
+// LDS map (dynamic, 16-B aligned), LCAP = 64 * NW:
+//   [0, 4*LCAP) int list[] | [4*LCAP, 8*LCAP) uint32 zr[] | [8*LCAP, +128) int wcnt[2][16] |
+//   union { dcap x STRIDE candidate bytes ; (CR*16 rows) x RS floats out tile, RS = 4*NW + pad ((RS/4) odd) }
 __host__ __device__ __forceinline__ int row_stride_floats(int NW) { return 4 * NW + ((NW & 1) ? 8 : 4); }
-__host__ __device__ __forceinline__ int cand_stride_bytes(int ct) { return 48 + (ct < 4 ? 16 : 4 * ct); }
+__host__ __device__ __forceinline__ int cand_stride_bytes(int ct) { return 64 + (ct < 4 ? 16 : 4 * ct); }
 
-size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t *dcap, int32_t *union_bytes) {
-    const int stride = cand_stride_bytes(ct);
+size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t *dcap) {
     const int cr = ct < 16 ? ct : 16;
-    const int lcap = 64 * NW;
-    const size_t tile = (size_t)cr * 16 * row_stride_floats(NW) * 4;
-    size_t un = tile;
+    const int stride = cand_stride_bytes(ct);
+    size_t un = (size_t)cr * 16 * row_stride_floats(NW) * 4;
     const size_t min_cand = (size_t)96 * stride;
     if (un < min_cand) un = min_cand;
     int cap = (int)(un / stride);
-    if (cap > lcap) cap = lcap;
-    *dcap = cap;
-    *union_bytes = (int32_t)un;
-    return (size_t)8 * lcap + 128 + un;
+    if (cap > 64 * NW) cap = 64 * NW;
+    if (dcap) *dcap = cap;
+    return (size_t)8 * 64 * NW + 128 + un;
 }
 
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
-__global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
+// VARIANT: 0 = every channel chunk is full (C % CT == 0) and one radius per atom: fast path;
+//          1 = partial channel chunks (any C); 2 = channel-wise radii (per-channel membership, any C)
+template <int CT, int MODE, bool GAUSS, int VARIANT, bool LANE_RANGE, int MAXT>
+__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
+    voxelize_kernel(const AtomRec *__restrict__ rec, const float *__restrict__ features,
+                    const uint4 *__restrict__ xlist, const int *__restrict__ xcount,
+                    const int64_t *__restrict__ offsets, const double *__restrict__ Tc,
+                    const float *__restrict__ kc, float *__restrict__ out, const VoxParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STRIDE = 48 + (CT < 4 ? 16 : 4 * CT); // bytes, multiple of 16
-    constexpr int WT = 12 + CT;                          // words staged per candidate
-    constexpr int CR = CT < 16 ? CT : 16;                // channels per write-out round
+    constexpr int CR = CT < 16 ? CT : 16; // channels per write-out round
     constexpr int NROUND = CT / CR;
+    constexpr int STRIDE = 64 + (CT < 4 ? 16 : 4 * CT);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = A.NW;
+    const int NW = P.NW;
     const int nthreads = NW * 64;
     const int LCAP = nthreads;
-    const int D = A.D;
+    const int D = P.D;
 
     int *list = reinterpret_cast<int *>(smem);
     unsigned *zr_l = reinterpret_cast<unsigned *>(smem + 4 * LCAP);
     int *wcnt = reinterpret_cast<int *>(smem + 8 * LCAP);
     char *un = smem + 8 * LCAP + 128;
+    float *tile = reinterpret_cast<float *>(un);
 
     // ---- block -> (molecule, channel chunk, slab) -------------------------------------------------
+    // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, observed, speed only). Remap so
+    // that the nzc z-chunks of one (x, y) column run on the same XCD back to back: their runs are pieces of the
+    // same rows, so that XCD's L2 sees whole rows. Bijective on the leading multiple of 8*nzc.
     int bid = blockIdx.x;
-    const int zc = bid % A.nzc;
-    bid /= A.nzc;
-    const int sy = bid % A.nsx;
-    bid /= A.nsx;
-    const int sx = bid % A.nsx;
-    bid /= A.nsx;
-    const int cc = bid % A.ncc;
-    const int b = bid / A.ncc;
+    if (P.xcd_remap) {
+        const int G = 8 * P.nzc;
+        const int full = (int)(gridDim.x / G) * G;
+        if (bid < full) {
+            const int xcd = bid & 7, slot = bid >> 3;
+            bid = ((slot / P.nzc) * 8 + xcd) * P.nzc + (slot % P.nzc);
+        }
+    }
+    const int zc = bid % P.nzc;
+    bid /= P.nzc;
+    const int sy = bid % P.nsx;
+    bid /= P.nsx;
+    const int sx = bid % P.nsx;
+    bid /= P.nsx;
+    const int cc = bid % P.ncc;
+    const int b = bid / P.ncc;
     const int cbase = cc * 32;
 
     const int x0 = 4 * sx, y0 = 4 * sy, z0 = zc * 4 * NW;
     const int zhi_slab = z0 + 4 * NW - 1;
-    const int64_t a0 = A.offsets[b];
-    const int nmol = (int)(A.offsets[b + 1] - a0);
-    const uint4 *xl = A.xlist + a0 * A.nsx + (int64_t)sx * nmol;
-    const int nx = A.xcount[b * A.nsx + sx];
+    // x-list of (b, sx): fixed-stride region, so the first entry load does not wait for any other load
+    const uint4 *__restrict__ xl = xlist + ((size_t)b * P.nsx + sx) * (size_t)P.xstride;
+    uint4 e0 = make_uint4(0u, 0x0000ffffu, 0x0000ffffu, 0u);
+    if (tid < P.xstride) e0 = xl[tid];
+    const int nx = (P.ablate & 2) ? 0 : xcount[b * P.nsx + sx];
+    const int64_t a0 = offsets[b];
 
     // ---- this lane's voxel ---------------------------------------------------------------------
     const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
     const int ix = x0 + lx, iy = y0 + ly, iz = z0 + 4 * wave + lz;
-    const double gx = (double)ix * A.res - A.half; // axis[i] = i*res - width/2, numpy/voxelizer.py:41-43
-    const double gy = (double)iy * A.res - A.half;
-    const double gz = (double)iz * A.res - A.half;
+    const double gx = (double)ix * P.res - P.half; // axis[i] = i*res - width/2, numpy/voxelizer.py:41-43
+    const double gy = (double)iy * P.res - P.half;
+    const double gz = (double)iz * P.res - P.half;
     const int zlo_w = z0 + 4 * wave, zhi_w = zlo_w + 3;
 
     float2v acc[(CT + 1) / 2];
@@ -398,12 +425,11 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
         while (cursor < nx && nlist + nthreads <= LCAP) {
             const int i = cursor + tid;
             bool m = false;
-            uint4 e = make_uint4(0, 0, 0, 0);
-            if (i < nx) {
-                e = xl[i];
+            uint4 e = e0;
+            if (cursor > 0 && i < nx) e = xl[i];
+            if (i < nx)
                 m = ((int)(e.y & 0xffff) <= y0 + 3) && ((int)(e.y >> 16) >= y0) && ((int)(e.z & 0xffff) <= zhi_slab) &&
                     ((int)(e.z >> 16) >= z0);
-            }
             const unsigned long long mask = __ballot(m);
             int *wc = wcnt + (phase & 1) * 16;
             if (lane == 0) wc[wave] = __popcll(mask);
@@ -436,30 +462,25 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
         if (nlist == 0) continue;
         any_candidate = true;
 
-        // ---- 2./3. stage candidates in chunks of dcap (flat, coalesced gather), accumulate ------
-        for (int c0 = 0; c0 < nlist; c0 += A.dcap) {
-            const int n = (nlist - c0) < A.dcap ? (nlist - c0) : A.dcap;
-            const int nwords = n * WT;
-            for (int i0 = tid; i0 < nwords; i0 += 4 * nthreads) {
-                unsigned v[4];
-                int dsti[4];
+        for (int c0 = 0; c0 < nlist; c0 += P.dcap) {
+            const int n = (nlist - c0) < P.dcap ? (nlist - c0) : P.dcap;
+            // ---- 2. stage: lanes 0-15 copy the 64-B record, lanes 16..16+CT-1 the feature row ---
+            for (int j0 = wave; j0 < n; j0 += 8 * NW) {
+                unsigned v[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u * nthreads;
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u * NW;
                     v[u] = 0u;
-                    dsti[u] = -1;
-                    if (i < nwords) {
-                        const int j = i / WT, w = i - j * WT;
+                    if (j < n) {
                         const int64_t a = a0 + list[c0 + j];
-                        dsti[u] = j * (STRIDE / 4) + w;
-                        if (w < 12) {
-                            v[u] = reinterpret_cast<const unsigned *>(A.rec + a)[w];
-                        } else {
-                            const int c = w - 12;
+                        if (lane < 16) {
+                            v[u] = reinterpret_cast<const unsigned *>(rec + a)[lane];
+                        } else if (lane < 16 + CT) {
+                            const int c = lane - 16;
                             float f = 0.0f;
-                            if (cbase + c < A.C) {
-                                if (A.mode == MODE_FEATURES) f = A.features[a * A.C + cbase + c];
-                                else if (A.mode == MODE_TYPES) f = (A.rec[a].type == cbase + c) ? 1.0f : 0.0f;
+                            if (cbase + c < P.C) {
+                                if (MODE == MODE_FEATURES) f = features[a * P.C + cbase + c];
+                                else if (MODE == MODE_TYPES) f = (rec[a].type == cbase + c) ? 1.0f : 0.0f;
                                 else f = 1.0f;
                             }
                             v[u] = __float_as_uint(f);
@@ -467,12 +488,15 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (dsti[u] >= 0) reinterpret_cast<unsigned *>(un)[dsti[u]] = v[u];
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u * NW;
+                    if (j < n && lane < 16 + CT) reinterpret_cast<unsigned *>(un + (size_t)j * STRIDE)[lane] = v[u];
+                }
             }
             __syncthreads();
 
-            for (int jb = 0; jb < n; jb += 64) {
+            // ---- 3. walk the candidates that touch this wave's sub-tile ------------------------------
+            for (int jb = 0; jb < ((P.ablate & 1) ? 0 : n); jb += 64) {
                 const int j = jb + lane;
                 bool ok = false;
                 if (j < n) {
@@ -486,46 +510,50 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
                     const char *r = un + (size_t)jj * STRIDE;
                     const double2 Pxy = *reinterpret_cast<const double2 *>(r);      // px, py
                     const double2 PzT = *reinterpret_cast<const double2 *>(r + 16); // pz, T
+                    const uint4 q = *reinterpret_cast<const uint4 *>(r + 32);       // k, type, xr, yr
                     const double dx = Pxy.x - gx, dy = Pxy.y - gy, dz = PzT.x - gz;
                     const double d2 = (dx * dx + dy * dy) + dz * dz; // cdist order, no fma
                     bool hit = d2 <= PzT.y;
                     if (LANE_RANGE) {
-                        const uint4 q = *reinterpret_cast<const uint4 *>(r + 32); // k, type, xr, yr
+                        const unsigned zr = *reinterpret_cast<const unsigned *>(r + 48);
                         hit = hit && (ix >= (int)(q.z & 0xffff)) && (ix <= (int)(q.z >> 16)) &&
-                              (iy >= (int)(q.w & 0xffff)) && (iy <= (int)(q.w >> 16));
-                        const unsigned zr = zr_l[c0 + jj];
-                        hit = hit && (iz >= (int)(zr & 0xffff)) && (iz <= (int)(zr >> 16));
+                              (iy >= (int)(q.w & 0xffff)) && (iy <= (int)(q.w >> 16)) && (iz >= (int)(zr & 0xffff)) &&
+                              (iz <= (int)(zr >> 16));
                     }
-                    if (__ballot(hit) == 0ull) continue;
-                    const float *f = reinterpret_cast<const float *>(r + 48);
                     const float d2f = (float)d2;
-                    if (!CHANWISE) {
-                        float val = 0.0f;
-                        if (hit) val = GAUSS ? __builtin_amdgcn_exp2f(*reinterpret_cast<const float *>(r + 32) * d2f) : 1.0f;
+                    const float *f = reinterpret_cast<const float *>(r + 64);
+                    float val = 0.0f;
+                    if (VARIANT != 2) {
+                        const float e = GAUSS ? __builtin_amdgcn_exp2f(__uint_as_float(q.x) * d2f) : 1.0f;
+                        val = hit ? e : 0.0f;
+                    }
+                    if constexpr (CT == 1) {
+                        float vc = val;
+                        if (VARIANT == 2) {
+                            const float e = GAUSS ? __builtin_amdgcn_exp2f(kc[cbase] * d2f) : 1.0f;
+                            vc = (hit && d2 <= Tc[cbase]) ? e : 0.0f;
+                        }
+                        acc[0].x = fmaf(vc, f[0], acc[0].x);
+                    } else if constexpr (VARIANT != 2) {
                         const float2v v2 = (float2v){val, val};
-                        if (CT == 1) {
-                            acc[0].x = fmaf(val, f[0], acc[0].x);
-                        } else {
 #pragma unroll
-                            for (int c = 0; c < CT / 2; ++c) {
-                                const float2v f2 = *reinterpret_cast<const float2v *>(f + 2 * c);
-                                acc[c] = __builtin_elementwise_fma(v2, f2, acc[c]);
-                            }
+                        for (int c = 0; c < CT / 2; ++c) {
+                            const float2v f2 = *reinterpret_cast<const float2v *>(f + 2 * c);
+                            acc[c] = __builtin_elementwise_fma(v2, f2, acc[c]);
                         }
                     } else {
 #pragma unroll
                         for (int c = 0; c < CT; ++c) {
-                            const int ch = cbase + c;
-                            float val = 0.0f;
-                            if (ch < A.C && hit && d2 <= A.Tc[ch])
-                                val = GAUSS ? __builtin_amdgcn_exp2f(A.kc[ch] * d2f) : 1.0f;
-                            if (c & 1) acc[c / 2].y = fmaf(val, f[c], acc[c / 2].y);
-                            else acc[c / 2].x = fmaf(val, f[c], acc[c / 2].x);
+                            const int ch = (cbase + c < P.C) ? cbase + c : P.C - 1;
+                            const float e = GAUSS ? __builtin_amdgcn_exp2f(kc[ch] * d2f) : 1.0f;
+                            const float vc = (hit && d2 <= Tc[ch]) ? e : 0.0f;
+                            if (c & 1) acc[c / 2].y = fmaf(vc, f[c], acc[c / 2].y);
+                            else acc[c / 2].x = fmaf(vc, f[c], acc[c / 2].x);
                         }
                     }
                 }
             }
-            __syncthreads(); // candidates consumed: the union region may be rewritten
+            __syncthreads(); // candidates consumed: the union region / list may be rewritten
         }
     }
 
@@ -537,15 +565,15 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
     const int zq = z0 + 4 * q;
     const int sxx = (rfirst >> 2) & 3, syy = rfirst & 3, cfirst = rfirst >> 4;
     const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
-    float *dst0 = A.out + ((size_t)b * A.C + cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
+    float *dst0 = out + ((size_t)b * P.C + cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
     if (!any_candidate) {
         // empty slab: pure zero fill with the same addressing (no LDS round trip)
         if (vox_ok) {
 #pragma unroll 4
             for (int c = cfirst; c < CT; c += 4) {
-                if (cbase + c >= A.C) break;
+                if (cbase + c >= P.C) break;
                 float *dst = dst0 + (size_t)(c - cfirst) * D3;
-                if (A.vec_store) {
+                if (P.vec_store) {
                     *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
                     for (int e = 0; e < 4; ++e)
@@ -555,7 +583,6 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
         }
         return;
     }
-    float *tile = reinterpret_cast<float *>(un);
     const int col = 4 * wave + lz;
     const int rxy = lx * 4 + ly;
 #pragma unroll
@@ -572,10 +599,10 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
 #pragma unroll
             for (int p = 0; p < (CR + 3) / 4; ++p) {
                 const int c = cfirst + 4 * p; // channel inside the round
-                if (c >= CR || cbase + rd * CR + c >= A.C) break;
+                if (c >= CR || cbase + rd * CR + c >= P.C) break;
                 const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 64 * p) * RS + 4 * q);
                 float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
-                if (A.vec_store) {
+                if (P.vec_store) {
                     *reinterpret_cast<float4 *>(dst) = v;
                 } else {
                     const float e4[4] = {v.x, v.y, v.z, v.w};
@@ -590,60 +617,81 @@ __global__ void __launch_bounds__(1024) voxelize_kernel(VoxArgs A) {
 // ------------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------------
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
-static hipError_t launch_one(const VoxArgs &a, size_t lds, hipStream_t s) {
-    const long long blocks = (long long)a.B * a.ncc * a.nsx * a.nsx * a.nzc;
-    if (blocks <= 0) return hipSuccess;
-    if (blocks > 0x7fffffffLL) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE>), dim3((unsigned)blocks), dim3(a.NW * 64),
-                       lds, s, a);
-    return hipGetLastError();
+struct KernelKey {
+    int ct, mode;
+    bool gauss;
+    int variant;
+    bool lane_range;
+    int maxt;
+};
+
+// Calls fn.template operator()<CT, MODE, GAUSS, VARIANT, LANE_RANGE, MAXT>() for the instantiation `k` names.
+template <typename Fn>
+static hipError_t for_kernel(const KernelKey &k, Fn &&fn) {
+#define MVX_CASE(CT_, MODE_, G_, V_, LR_, MT_)                                                               \
+    if (k.ct == CT_ && k.mode == MODE_ && k.gauss == G_ && k.variant == V_ && k.lane_range == LR_ && k.maxt == MT_) \
+        return fn.template operator()<CT_, MODE_, G_, V_, LR_, MT_>();
+#define MVX_CASES_GL(CT_, MODE_, V_, MT_)     \
+    MVX_CASE(CT_, MODE_, true, V_, false, MT_)  \
+    MVX_CASE(CT_, MODE_, false, V_, false, MT_) \
+    MVX_CASE(CT_, MODE_, true, V_, true, MT_)   \
+    MVX_CASE(CT_, MODE_, false, V_, true, MT_)
+#define MVX_CASES_CT(CT_, MT_)                      \
+    MVX_CASES_GL(CT_, MODE_FEATURES, 0, MT_)        \
+    MVX_CASES_GL(CT_, MODE_FEATURES, 1, MT_)        \
+    MVX_CASES_GL(CT_, MODE_TYPES, 0, MT_)           \
+    MVX_CASE(CT_, MODE_FEATURES, true, 2, true, MT_)  \
+    MVX_CASE(CT_, MODE_FEATURES, false, 2, true, MT_)
+#define MVX_CASES_MT(MT_)    \
+    MVX_CASES_CT(1, MT_)     \
+    MVX_CASES_CT(4, MT_)     \
+    MVX_CASES_CT(8, MT_)     \
+    MVX_CASES_CT(16, MT_)    \
+    MVX_CASES_CT(32, MT_)    \
+    MVX_CASES_GL(1, MODE_SINGLE, 0, MT_)
+    MVX_CASES_MT(512)
+    MVX_CASES_MT(1024)
+#undef MVX_CASES_MT
+#undef MVX_CASES_CT
+#undef MVX_CASES_GL
+#undef MVX_CASE
+    return hipErrorInvalidValue;
 }
 
-template <int CT>
-static hipError_t launch_ct(const VoxArgs &a, bool gauss, bool chanwise, bool lane_range, size_t lds, hipStream_t s) {
-    if (chanwise) return gauss ? launch_one<CT, true, true, true>(a, lds, s) : launch_one<CT, false, true, true>(a, lds, s);
-    if (lane_range) return gauss ? launch_one<CT, true, false, true>(a, lds, s) : launch_one<CT, false, false, true>(a, lds, s);
-    return gauss ? launch_one<CT, true, false, false>(a, lds, s) : launch_one<CT, false, false, false>(a, lds, s);
-}
+struct LaunchFn {
+    const VoxArgs &a;
+    hipStream_t s;
+    template <int CT, int MODE, bool GAUSS, int VARIANT, bool LANE_RANGE, int MAXT>
+    hipError_t operator()() const {
+        const long long blocks = (long long)a.p.B * a.p.ncc * a.p.nsx * a.p.nsx * a.p.nzc;
+        if (blocks <= 0) return hipSuccess;
+        if (blocks > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+        const size_t lds = voxelize_lds_bytes(CT, a.p.NW, nullptr);
+        if (lds > 64 * 1024) { // above the default dynamic-LDS limit: raise it once per instantiation
+            static size_t raised = 0;
+            if (lds > raised) {
+                hipError_t e = hipFuncSetAttribute(
+                    reinterpret_cast<const void *>(&voxelize_kernel<CT, MODE, GAUSS, VARIANT, LANE_RANGE, MAXT>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                raised = lds;
+            }
+        }
+        hipLaunchKernelGGL((voxelize_kernel<CT, MODE, GAUSS, VARIANT, LANE_RANGE, MAXT>), dim3((unsigned)blocks),
+                           dim3(a.p.NW * 64), lds, s, a.rec, a.features, a.xlist, a.xcount, a.offsets, a.Tc, a.kc,
+                           a.out, a.p);
+        return hipGetLastError();
+    }
+};
 
 hipError_t launch_voxelize(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {
-    int32_t dcap, ub;
-    const size_t lds = voxelize_lds_bytes(ct, a.NW, &dcap, &ub);
-    switch (ct) {
-    case 1: return launch_ct<1>(a, gauss, chanwise, lane_range, lds, s);
-    case 4: return launch_ct<4>(a, gauss, chanwise, lane_range, lds, s);
-    case 8: return launch_ct<8>(a, gauss, chanwise, lane_range, lds, s);
-    case 16: return launch_ct<16>(a, gauss, chanwise, lane_range, lds, s);
-    case 32: return launch_ct<32>(a, gauss, chanwise, lane_range, lds, s);
-    default: return hipErrorInvalidValue;
-    }
+    int variant = 0;
+    if (chanwise) variant = 2;
+    else if (a.p.mode == MODE_FEATURES && a.p.C % ct != 0) variant = 1;
+    KernelKey k{ct, a.p.mode, gauss, variant, variant == 2 ? true : lane_range, a.p.NW <= 8 ? 512 : 1024};
+    return for_kernel(k, LaunchFn{a, s});
 }
 
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
-static hipError_t raise_lds() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
-
-template <int CT>
-static hipError_t raise_lds_ct() {
-    hipError_t e;
-    if ((e = raise_lds<CT, true, true, true>()) != hipSuccess) return e;
-    if ((e = raise_lds<CT, false, true, true>()) != hipSuccess) return e;
-    if ((e = raise_lds<CT, true, false, true>()) != hipSuccess) return e;
-    if ((e = raise_lds<CT, false, false, true>()) != hipSuccess) return e;
-    if ((e = raise_lds<CT, true, false, false>()) != hipSuccess) return e;
-    return raise_lds<CT, false, false, false>();
-}
-
-hipError_t configure_kernels() {
-    hipError_t e;
-    if ((e = raise_lds_ct<1>()) != hipSuccess) return e;
-    if ((e = raise_lds_ct<4>()) != hipSuccess) return e;
-    if ((e = raise_lds_ct<8>()) != hipSuccess) return e;
-    if ((e = raise_lds_ct<16>()) != hipSuccess) return e;
-    return raise_lds_ct<32>();
-}
+hipError_t configure_kernels() { return hipSuccess; }
 
 } // namespace mvx
