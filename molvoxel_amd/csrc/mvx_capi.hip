@@ -65,7 +65,11 @@ struct mvx_handle {
     bool profiling = false;
     int force_nw = 0;
     int ablate = 0;
-    int xcd_remap = 1;
+    int want_stamps = 0;
+    size_t stamp_blocks = 0;
+    DevBuf stamps;
+    int row_bytes = 64;
+    int store_kind = 1; // nt: measured 0.69 -> 0.54 ms on cfg-2 (output lines do not displace the re-read inputs in L2)
 };
 
 namespace {
@@ -246,7 +250,12 @@ int run(mvx_handle *h, const RunArgs &r) {
 
     // ---- workspace --------------------------------------------------------------------------------
     const size_t n_alloc = (size_t)std::max<int64_t>(total, 1);
-    if ((rc = ensure(h->rec, n_alloc * sizeof(AtomRec)))) return rc;
+    const int ct = pick_ct(std::min(r.C, 32));
+    const int ncc = (r.C + 31) / 32;
+    const int Cpad = (ncc > 1) ? ncc * 32 : (ct < 4 ? 4 : ct); // channel weights per row, zero padded
+    const int row_words = 16 + Cpad;
+    if ((rc = ensure(h->rec, n_alloc * (size_t)row_words * 4))) return rc;
+    h->row_bytes = row_words * 4;
     if ((rc = ensure(h->bbox, n_alloc * sizeof(uint4)))) return rc;
 
     const bool gauss = (h->cfg.density == MVX_GAUSSIAN);
@@ -281,15 +290,19 @@ int run(mvx_handle *h, const RunArgs &r) {
     pa.density = h->cfg.density;
     pa.sigma32 = h->sigma32;
     pa.g = g;
-    pa.rec = reinterpret_cast<AtomRec *>(h->rec.p);
+    pa.rows = reinterpret_cast<char *>(h->rec.p);
+    pa.row_bytes = row_words * 4;
     pa.bbox = reinterpret_cast<uint4 *>(h->bbox.p);
     HIP_TRY(launch_prep(pa, s));
+    HIP_TRY(launch_pack_channels(reinterpret_cast<float *>(h->rec.p), row_words, Cpad, r.C, r.mode,
+                                 (r.mode == MODE_FEATURES) ? reinterpret_cast<const float *>(d_chan) : nullptr,
+                                 (r.mode == MODE_TYPES) ? reinterpret_cast<const int32_t *>(d_chan) : nullptr, total, s));
 
     // ---- voxelize ---------------------------------------------------------------------------------
     VoxArgs va;
-    va.rec = pa.rec;
+    va.rows = reinterpret_cast<const unsigned *>(h->rec.p);
+    va.p.row_words = row_words;
     va.offsets = d_off;
-    va.features = (r.mode == MODE_FEATURES) ? reinterpret_cast<const float *>(d_chan) : nullptr;
     va.Tc = d_Tc;
     va.kc = d_kc;
     va.out = d_out;
@@ -314,25 +327,32 @@ int run(mvx_handle *h, const RunArgs &r) {
         nzc = (nz4 + NW - 1) / NW;
     }
     va.p.nsx = nz4;
+    va.p.nsx_inv = (uint32_t)(((1u << 24) + (uint32_t)nz4 - 1u) / (uint32_t)nz4);
     va.p.nzc = nzc;
     va.p.NW = NW;
     // x-slab binning (ordered lists per (molecule, x-slab), fixed-stride regions)
     int64_t nmax = 1;
     for (int b = 0; b < r.B; ++b) nmax = std::max<int64_t>(nmax, r.offsets[b + 1] - r.offsets[b]);
-    if ((rc = ensure(h->xlist, (size_t)r.B * nz4 * (size_t)nmax * sizeof(uint4)))) return rc;
+    if ((rc = ensure(h->xlist, (size_t)r.B * nz4 * (size_t)nmax * sizeof(uint2)))) return rc;
     if ((rc = ensure(h->xcount, (size_t)r.B * nz4 * sizeof(int)))) return rc;
-    HIP_TRY(launch_xbin(pa.bbox, d_off, r.B, nz4, (int32_t)nmax, reinterpret_cast<uint4 *>(h->xlist.p),
+    HIP_TRY(launch_xbin(pa.bbox, d_off, r.B, nz4, (int32_t)nmax, reinterpret_cast<uint2 *>(h->xlist.p),
                         reinterpret_cast<int *>(h->xcount.p), s));
     va.p.xstride = (int32_t)nmax;
-    va.xlist = reinterpret_cast<const uint4 *>(h->xlist.p);
+    va.xlist = reinterpret_cast<const uint2 *>(h->xlist.p);
     va.xcount = reinterpret_cast<const int *>(h->xcount.p);
-    va.p.ncc = (r.C + 31) / 32;
-    va.p.mode = r.mode;
+    va.p.ncc = ncc;
+    va.p.dcap = voxelize_dcap(ct, NW);
     va.p.vec_store = (D % 4 == 0) ? 1 : 0;
     va.p.ablate = h->ablate;
-    va.p.xcd_remap = (h->xcd_remap && nzc > 1) ? 1 : 0;
-    const int ct = pick_ct(std::min(r.C, 32));
-    (void)voxelize_lds_bytes(ct, NW, &va.p.dcap);
+    va.p.stamps = nullptr;
+    if (h->want_stamps) {
+        const size_t nblk = (size_t)r.B * ncc * nz4 * nz4 * nzc;
+        if ((rc = ensure(h->stamps, nblk * 8 * sizeof(unsigned long long)))) return rc;
+        HIP_TRY(hipMemsetAsync(h->stamps.p, 0, nblk * 8 * sizeof(unsigned long long), s));
+        va.p.stamps = reinterpret_cast<unsigned long long *>(h->stamps.p);
+        h->stamp_blocks = nblk;
+    }
+    va.p.store_kind = h->store_kind;
     // a 4^3 sub-tile lies inside one reference block when 4 | blockdim (or there is a single block):
     // the block cull is then wave-uniform and already folded into the candidate ranges.
     const bool lane_range = !(g.nb == 1 || g.bd % 4 == 0);
@@ -381,7 +401,7 @@ int mvx_create(const mvx_config *cfg, mvx_handle **out) {
     if (!cfg || !out) return fail(MVX_ERR_INVALID, "null argument");
     *out = nullptr;
     if (!(cfg->resolution > 0.0)) return fail(MVX_ERR_INVALID, "resolution must be > 0");
-    if (cfg->dimension < 1 || cfg->dimension > 4096) return fail(MVX_ERR_INVALID, "dimension must be in [1, 4096]");
+    if (cfg->dimension < 1 || cfg->dimension > 1020) return fail(MVX_ERR_INVALID, "dimension must be in [1, 1020]");
     if (cfg->density != MVX_GAUSSIAN && cfg->density != MVX_BINARY) return fail(MVX_ERR_INVALID, "bad density");
     if (cfg->density == MVX_GAUSSIAN && !(cfg->sigma > 0.0)) return fail(MVX_ERR_INVALID, "sigma must be > 0");
     int n = 0;
@@ -399,7 +419,8 @@ int mvx_create(const mvx_config *cfg, mvx_handle **out) {
     make_geom(h);
     if (const char *env = std::getenv("MVX_NW")) h->force_nw = std::atoi(env);
     if (const char *env = std::getenv("MVX_ABLATE")) h->ablate = std::atoi(env);
-    if (const char *env = std::getenv("MVX_XCD_REMAP")) h->xcd_remap = std::atoi(env);
+    if (const char *env = std::getenv("MVX_STAMPS")) h->want_stamps = std::atoi(env);
+    if (const char *env = std::getenv("MVX_STORE")) h->store_kind = std::atoi(env);
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) {
         delete h;
@@ -566,13 +587,24 @@ int mvx_last_kernel_ms(mvx_handle *h, float *ms) {
     return MVX_OK;
 }
 
+int mvx_debug_read_stamps(mvx_handle *h, void *host_dst, int64_t max_blocks, int64_t *blocks) {
+    if (!h || !host_dst || !blocks) return fail(MVX_ERR_INVALID, "bad argument");
+    DeviceGuard guard(h->device);
+    const size_t n = std::min<size_t>(h->stamp_blocks, (size_t)max_blocks);
+    HIP_TRY(hipDeviceSynchronize());
+    if (n) HIP_TRY(hipMemcpy(host_dst, h->stamps.p, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    *blocks = (int64_t)n;
+    return MVX_OK;
+}
+
 int mvx_debug_read_records(mvx_handle *h, void *host_dst, int64_t n, void *stream) {
     if (!h || !host_dst || n < 0) return fail(MVX_ERR_INVALID, "bad argument");
-    if ((size_t)n * sizeof(AtomRec) > h->rec.cap) return fail(MVX_ERR_INVALID, "more records requested than the workspace holds");
+    if ((size_t)n * (size_t)h->row_bytes > h->rec.cap) return fail(MVX_ERR_INVALID, "more records requested than the workspace holds");
     if (n == 0) return MVX_OK;
     DeviceGuard guard(h->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemcpyAsync(host_dst, h->rec.p, (size_t)n * sizeof(AtomRec), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpy2DAsync(host_dst, sizeof(AtomRec), h->rec.p, (size_t)h->row_bytes, sizeof(AtomRec), (size_t)n,
+                             hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return MVX_OK;
 }

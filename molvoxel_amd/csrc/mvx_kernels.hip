@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
     R.xr = rng[0];
     R.yr = rng[1];
     R.zr = rng[2];
-    A.rec[a] = R;
+    *reinterpret_cast<AtomRec *>(A.rows + (size_t)a * A.row_bytes) = R; // row = 64-B record + padded channel weights
     A.bbox[a] = make_uint4(rng[0], rng[1], rng[2], 0u);
 }
 
@@ -273,19 +273,54 @@ hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf
 }
 
 // ------------------------------------------------------------------------------------------------
+// channel weights: features / one-hot types / ones, padded with zeros, behind each atom's record
+// ------------------------------------------------------------------------------------------------
+// Row a = [AtomRec 64 B | Cpad floats]. forward_features copies F[a, :] (numpy/voxelizer.py:233: out = F^T @ res),
+// forward_types writes the one-hot of types[a] (out[type] += res, :364-365), forward_single a single 1 (:476).
+// The voxelize kernel then reads one contiguous row per candidate whatever the operator was.
+__global__ void __launch_bounds__(256)
+    pack_channels_kernel(float *rows, int row_words, int Cpad, int C, int mode, const float *__restrict__ features,
+                         const int32_t *__restrict__ types, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total * Cpad) return;
+    const int64_t a = idx / Cpad;
+    const int c = (int)(idx - a * Cpad);
+    float f = 0.0f;
+    if (c < C) {
+        if (mode == MODE_FEATURES) f = features[a * C + c];
+        else if (mode == MODE_TYPES) f = (types[a] == c) ? 1.0f : 0.0f;
+        else f = 1.0f;
+    }
+    rows[a * row_words + 16 + c] = f;
+}
+
+hipError_t launch_pack_channels(float *rows, int32_t row_words, int32_t Cpad, int32_t C, int32_t mode,
+                                const float *features, const int32_t *types, int64_t total, hipStream_t s) {
+    if (total <= 0) return hipSuccess;
+    const int64_t n = total * Cpad;
+    hipLaunchKernelGGL(pack_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, row_words, Cpad, C,
+                       mode, features, types, total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // x-slab binning: ordered list of the atoms whose admitted x-range touches each 4-voxel x-slab
 // ------------------------------------------------------------------------------------------------
 // One wave per (molecule, x-slab). Entries keep atom order (ballot + prefix compaction, no atomics,
-// so downstream float sums are reproducible). Entry = {atom index in molecule, yr, zr, 0}; list
+// so downstream float sums are reproducible). Entry = {atom index in molecule, packed slab ranges}: the
+// admitted y range in 4-voxel slabs (lo | hi << 8) and the admitted z range in 4-voxel sub-tiles
+// (lo << 16 | hi << 24); that is all the voxelize kernel's slab / sub-tile filters need (D <= 1024). List
 // (b, sx) lives at xlist[(b*nsx + sx) * xstride] (xstride = largest molecule of the batch), its length in
 // xcount[b*nsx+sx].
+constexpr uint32_t EMPTY_ENTRY = 0x00ff00ffu; // y lo = z lo = 255, hi = 0: matches no slab
+
 __global__ void __launch_bounds__(64) xbin_kernel(const uint4 *bbox, const int64_t *offsets, int nsx, int xstride,
-                                                  uint4 *xlist, int *xcount) {
+                                                  uint2 *xlist, int *xcount) {
     const int b = blockIdx.x / nsx, sx = blockIdx.x % nsx;
     const int lane = threadIdx.x;
     const int64_t a0 = offsets[b], a1 = offsets[b + 1];
     const int x0 = 4 * sx;
-    uint4 *dst = xlist + (size_t)blockIdx.x * (size_t)xstride; // fixed stride: addressable from blockIdx alone
+    uint2 *dst = xlist + (size_t)blockIdx.x * (size_t)xstride; // fixed stride: addressable from blockIdx alone
     int count = 0;
     for (int64_t base = a0; base < a1; base += 64) {
         const int64_t a = base + lane;
@@ -298,14 +333,16 @@ __global__ void __launch_bounds__(64) xbin_kernel(const uint4 *bbox, const int64
         const unsigned long long mask = __ballot(m);
         if (m) {
             const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-            dst[count + below] = make_uint4((unsigned)(a - a0), bb.y, bb.z, 0u);
+            const unsigned packed = ((bb.y & 0xffff) >> 2) | (((bb.y >> 16) >> 2) << 8) | (((bb.z & 0xffff) >> 2) << 16) |
+                                    (((bb.z >> 16) >> 2) << 24);
+            dst[count + below] = make_uint2((unsigned)(a - a0), packed);
         }
         count += __popcll(mask);
     }
     if (lane == 0) xcount[blockIdx.x] = count;
 }
 
-hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, int32_t xstride, uint4 *xlist,
+hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, int32_t xstride, uint2 *xlist,
                        int *xcount, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(64), 0, s, bbox, offsets, nsx, xstride, xlist,
@@ -317,92 +354,112 @@ hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int
 // voxelize
 // ------------------------------------------------------------------------------------------------
 // One workgroup = one slab of 4 x 4 x (4*NW) voxels; one wave = one 4^3 sub-tile; one lane = one voxel with
-// CT channel accumulators in registers.
-//   1. scan: every thread loads one entry of the slab's x-list (address known from blockIdx alone, so the load
-//      is in flight while the list length is still being fetched) and tests its y/z ranges against the slab;
-//      matches are compacted in atom order (ballot + cross-wave prefix, one barrier) into an LDS list;
-//   2. stage: wave w copies candidates w, w+NW, ... (64-B record + CT feature floats, one coalesced load each,
-//      up to 8 in flight) into LDS; one barrier;
+// CT channel accumulators in registers. grid = (z chunk, sx*nsx + sy, molecule*ncc + channel chunk).
+//   1. scan (wave 0 only, the others wait at the barrier): up to 8 entries per lane of the slab's x-list are
+//      loaded at once (the list sits at a fixed stride, so the loads are in flight while the list length is
+//      still being fetched) and tested against the slab's y/z box; matches are compacted in atom order (ballot +
+//      running count, no cross-wave exchange) into an LDS list;
+//   2. stage: wave w copies the rows of candidates w, w+NW, ... (64-B record + CT channel weights; one coalesced
+//      load each, up to 8 in flight) into LDS; one barrier;
 //   3. walk: each wave picks the candidates whose z range touches its sub-tile (lane-parallel filter + ballot)
 //      and processes them: broadcast LDS reads, fp64 d2 in cdist order, compare with T, exp2, packed FMAs;
-//   4. write-out: accumulators -> LDS tile (CR = min(CT,16) channels per round) -> 16-B/lane stores in
-//      whole-row runs. Empty slabs skip the LDS round trip.
-// LDS map (dynamic, 16-B aligned), LCAP = 64 * NW:
-//   [0, 4*LCAP) int list[] | [4*LCAP, 8*LCAP) uint32 zr[] | [8*LCAP, +128) int wcnt[2][16] |
-//   union { dcap x STRIDE candidate bytes ; (CR*16 rows) x RS floats out tile, RS = 4*NW + pad ((RS/4) odd) }
-__host__ __device__ __forceinline__ int row_stride_floats(int NW) { return 4 * NW + ((NW & 1) ? 8 : 4); }
-__host__ __device__ __forceinline__ int cand_stride_bytes(int ct) { return 64 + (ct < 4 ? 16 : 4 * ct); }
+//   4. write-out: accumulators -> LDS tile (CR = min(CT,16) channels per round) -> non-temporal 16-B/lane
+//      stores in whole-row runs. Empty slabs skip the LDS round trip.
+// LDS map (dynamic, 16-B aligned), LCAP = 64 * min(NW, 8):
+//   [0, 4*LCAP) int list[] | [4*LCAP, 8*LCAP) uint32 zr[] | [8*LCAP, +16) int nlist |
+//   union { LCAP x SW words of candidate rows ; (CR*16 rows) x RS floats out tile, RS = 4*NW + pad ((RS/4) odd) }
 
-size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t *dcap) {
-    const int cr = ct < 16 ? ct : 16;
-    const int stride = cand_stride_bytes(ct);
-    size_t un = (size_t)cr * 16 * row_stride_floats(NW) * 4;
-    const size_t min_cand = (size_t)96 * stride;
-    if (un < min_cand) un = min_cand;
-    int cap = (int)(un / stride);
-    if (cap > 64 * NW) cap = 64 * NW;
-    if (dcap) *dcap = cap;
-    return (size_t)8 * 64 * NW + 128 + un;
+// 16-B output store. kind 0: plain (line stays in the XCD's L2); 1: nt; 2: sc1 (write-through). Output bytes are
+// written once and never re-read here; nt keeps them from displacing the re-read inputs (0.69 -> 0.54 ms, cfg-2).
+__device__ __forceinline__ void store_f4(float *dst, const float4 v, int kind) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 x = {v.x, v.y, v.z, v.w};
+    if (kind == 1) {
+        __builtin_nontemporal_store(x, reinterpret_cast<f4 *>(dst));
+    } else if (kind == 2) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(x) : "memory");
+    } else {
+        *reinterpret_cast<f4 *>(dst) = x;
+    }
 }
 
-// VARIANT: 0 = every channel chunk is full (C % CT == 0) and one radius per atom: fast path;
-//          1 = partial channel chunks (any C); 2 = channel-wise radii (per-channel membership, any C)
-template <int CT, int MODE, bool GAUSS, int VARIANT, bool LANE_RANGE, int MAXT>
+__host__ __device__ __forceinline__ int row_stride_floats(int NW) { return 4 * NW + ((NW & 1) ? 8 : 4); }
+__host__ __device__ __forceinline__ int cand_stride_words(int ct) { return 16 + (ct < 4 ? 4 : ct); }
+
+// candidate rows staged per round: what fits in the out tile's bytes, at least 64, at most the list capacity
+int32_t voxelize_dcap(int32_t ct, int32_t NW) {
+    const int cr = ct < 16 ? ct : 16;
+    const int lcap = 64 * (NW < 8 ? NW : 8);
+    const size_t tile = (size_t)cr * 16 * row_stride_floats(NW) * 4;
+    int cap = (int)(tile / ((size_t)cand_stride_words(ct) * 4));
+    if (cap < 64) cap = 64;
+    if (cap > lcap) cap = lcap;
+    return cap;
+}
+
+size_t voxelize_lds_bytes(int32_t ct, int32_t NW) {
+    const int cr = ct < 16 ? ct : 16;
+    const int lcap = 64 * (NW < 8 ? NW : 8);
+    const size_t tile = (size_t)cr * 16 * row_stride_floats(NW) * 4;
+    const size_t cand = (size_t)voxelize_dcap(ct, NW) * cand_stride_words(ct) * 4;
+    return (size_t)8 * lcap + 16 + (tile > cand ? tile : cand);
+}
+
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
-    voxelize_kernel(const AtomRec *__restrict__ rec, const float *__restrict__ features,
-                    const uint4 *__restrict__ xlist, const int *__restrict__ xcount,
-                    const int64_t *__restrict__ offsets, const double *__restrict__ Tc,
-                    const float *__restrict__ kc, float *__restrict__ out, const VoxParams P) {
+    voxelize_kernel(const unsigned *__restrict__ rows, const uint2 *__restrict__ xlist,
+                    const int *__restrict__ xcount, const int64_t *__restrict__ offsets,
+                    const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
+                    const VoxParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CR = CT < 16 ? CT : 16; // channels per write-out round
     constexpr int NROUND = CT / CR;
-    constexpr int STRIDE = 64 + (CT < 4 ? 16 : 4 * CT);
+    constexpr int SW = 16 + (CT < 4 ? 4 : CT); // LDS words per candidate (multiple of 4)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // diagnostic builds only (MVX_STAMPS): phase time stamps of thread 0 into a buffer nothing else reads
+    const size_t blk = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+#define MVX_STAMP(k) \
+    if (P.stamps && tid == 0) P.stamps[blk * 8 + (k)] = __builtin_amdgcn_s_memtime();
+    MVX_STAMP(0)
     const int NW = P.NW;
-    const int nthreads = NW * 64;
-    const int LCAP = nthreads;
+    const int SB = NW < 8 ? NW : 8; // x-list entries per lane and scan round
+    const int LCAP = 64 * SB;
     const int D = P.D;
 
     int *list = reinterpret_cast<int *>(smem);
     unsigned *zr_l = reinterpret_cast<unsigned *>(smem + 4 * LCAP);
-    int *wcnt = reinterpret_cast<int *>(smem + 8 * LCAP);
-    char *un = smem + 8 * LCAP + 128;
+    int *nlist_s = reinterpret_cast<int *>(smem + 8 * LCAP);
+    unsigned *un = reinterpret_cast<unsigned *>(smem + 8 * LCAP + 16);
     float *tile = reinterpret_cast<float *>(un);
 
     // ---- block -> (molecule, channel chunk, slab) -------------------------------------------------
-    // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, observed, speed only). Remap so
-    // that the nzc z-chunks of one (x, y) column run on the same XCD back to back: their runs are pieces of the
-    // same rows, so that XCD's L2 sees whole rows. Bijective on the leading multiple of 8*nzc.
-    int bid = blockIdx.x;
-    if (P.xcd_remap) {
-        const int G = 8 * P.nzc;
-        const int full = (int)(gridDim.x / G) * G;
-        if (bid < full) {
-            const int xcd = bid & 7, slot = bid >> 3;
-            bid = ((slot / P.nzc) * 8 + xcd) * P.nzc + (slot % P.nzc);
+    const int zc = blockIdx.x;
+    const int sx = (int)((blockIdx.y * (unsigned)P.nsx_inv) >> 24); // blockIdx.y / nsx (exact: y < 2^16, nsx <= 256)
+    const int sy = blockIdx.y - sx * P.nsx;
+    int b = blockIdx.z, cc = 0;
+    if (P.ncc > 1) {
+        b = blockIdx.z / P.ncc;
+        cc = blockIdx.z - b * P.ncc;
+    }
+    const int x0 = 4 * sx, y0 = 4 * sy, z0 = zc * 4 * NW;
+    const int zt_lo = zc * NW, zt_hi = zt_lo + NW - 1; // sub-tile index range of the slab along z
+    // x-list of (b, sx): fixed-stride region, so the entry loads do not wait for any other load
+    const uint2 *__restrict__ xl = xlist + ((size_t)b * P.nsx + sx) * (size_t)P.xstride;
+    const uint2 kEmpty = make_uint2(0u, EMPTY_ENTRY);
+    uint2 e[8];
+    if (wave == 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = u * 64 + lane;
+            e[u] = (u < SB && i < P.xstride) ? xl[i] : kEmpty;
         }
     }
-    const int zc = bid % P.nzc;
-    bid /= P.nzc;
-    const int sy = bid % P.nsx;
-    bid /= P.nsx;
-    const int sx = bid % P.nsx;
-    bid /= P.nsx;
-    const int cc = bid % P.ncc;
-    const int b = bid / P.ncc;
-    const int cbase = cc * 32;
-
-    const int x0 = 4 * sx, y0 = 4 * sy, z0 = zc * 4 * NW;
-    const int zhi_slab = z0 + 4 * NW - 1;
-    // x-list of (b, sx): fixed-stride region, so the first entry load does not wait for any other load
-    const uint4 *__restrict__ xl = xlist + ((size_t)b * P.nsx + sx) * (size_t)P.xstride;
-    uint4 e0 = make_uint4(0u, 0x0000ffffu, 0x0000ffffu, 0u);
-    if (tid < P.xstride) e0 = xl[tid];
     const int nx = (P.ablate & 2) ? 0 : xcount[b * P.nsx + sx];
     const int64_t a0 = offsets[b];
+    MVX_STAMP(1)
 
     // ---- this lane's voxel ---------------------------------------------------------------------
     const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
@@ -410,90 +467,65 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
     const double gx = (double)ix * P.res - P.half; // axis[i] = i*res - width/2, numpy/voxelizer.py:41-43
     const double gy = (double)iy * P.res - P.half;
     const double gz = (double)iz * P.res - P.half;
-    const int zlo_w = z0 + 4 * wave, zhi_w = zlo_w + 3;
+    const int zt_w = zt_lo + wave; // this wave's sub-tile index along z
+    // row word this lane stages: 0-15 record, 16.. the CT channel weights of chunk cc
+    const int lane_word = lane < 16 ? lane : lane + cc * 32;
+    const bool stager = lane < 16 + CT;
 
     float2v acc[(CT + 1) / 2];
 #pragma unroll
     for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
 
     bool any_candidate = false;
-    int cursor = 0;
-    int phase = 0;
-    while (cursor < nx) {
-        // ---- 1. ordered compaction of the x-slab list against this slab's y/z box ----------------
-        int nlist = 0;
-        while (cursor < nx && nlist + nthreads <= LCAP) {
-            const int i = cursor + tid;
-            bool m = false;
-            uint4 e = e0;
-            if (cursor > 0 && i < nx) e = xl[i];
-            if (i < nx)
-                m = ((int)(e.y & 0xffff) <= y0 + 3) && ((int)(e.y >> 16) >= y0) && ((int)(e.z & 0xffff) <= zhi_slab) &&
-                    ((int)(e.z >> 16) >= z0);
-            const unsigned long long mask = __ballot(m);
-            int *wc = wcnt + (phase & 1) * 16;
-            if (lane == 0) wc[wave] = __popcll(mask);
-            __syncthreads();
-            int pre = 0, tot = 0;
+    for (int base = 0; base < nx; base += LCAP) {
+        // ---- 1. wave 0: ordered compaction of LCAP x-list entries against the slab's y/z box ---------
+        if (wave == 0) {
+            int n = 0;
 #pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) {
-                const int4 c4 = *reinterpret_cast<const int4 *>(wc + 4 * w4);
-                const int cs[4] = {c4.x, c4.y, c4.z, c4.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int w = 4 * w4 + k;
-                    const int c = (w < NW) ? cs[k] : 0;
-                    tot += c;
-                    pre += (w < wave) ? c : 0;
+            for (int u = 0; u < 8; ++u) {
+                if (u < SB) {
+                    const int i = base + u * 64 + lane;
+                    uint2 en = e[u];
+                    if (base > 0) en = (i < nx) ? xl[i] : kEmpty;
+                    // packed slab ranges: y lo | y hi << 8 | z sub-tile lo << 16 | z sub-tile hi << 24
+                    const bool m = (i < nx) && ((int)(en.y & 0xff) <= sy) && ((int)((en.y >> 8) & 0xff) >= sy) &&
+                                   ((int)((en.y >> 16) & 0xff) <= zt_hi) && ((int)(en.y >> 24) >= zt_lo);
+                    const unsigned long long mask = __ballot(m);
+                    if (m) {
+                        const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        list[pos] = (int)en.x;
+                        zr_l[pos] = en.y;
+                    }
+                    n += __popcll(mask);
                 }
             }
-            if (m) {
-                const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                const int pos = nlist + pre + below;
-                list[pos] = (int)e.x;
-                zr_l[pos] = e.z;
-            }
-            nlist += tot;
-            cursor += nthreads;
-            ++phase;
+            if (lane == 0) nlist_s[0] = n;
         }
         __syncthreads(); // list complete
-        if (nlist == 0) continue;
-        any_candidate = true;
-
-        for (int c0 = 0; c0 < nlist; c0 += P.dcap) {
-            const int n = (nlist - c0) < P.dcap ? (nlist - c0) : P.dcap;
-            // ---- 2. stage: lanes 0-15 copy the 64-B record, lanes 16..16+CT-1 the feature row ---
+        const int nl = nlist_s[0];
+        MVX_STAMP(2)
+        for (int c0 = 0; c0 < nl; c0 += P.dcap) {
+            const int n = (nl - c0) < P.dcap ? (nl - c0) : P.dcap; // rows staged this round
+            if (c0 > 0) __syncthreads(); // previous round's rows consumed
+            any_candidate = true;
+            // ---- 2. stage rows: lanes 0-15 the 64-B record, lanes 16..16+CT-1 the channel weights -------
             for (int j0 = wave; j0 < n; j0 += 8 * NW) {
                 unsigned v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int j = j0 + u * NW;
                     v[u] = 0u;
-                    if (j < n) {
-                        const int64_t a = a0 + list[c0 + j];
-                        if (lane < 16) {
-                            v[u] = reinterpret_cast<const unsigned *>(rec + a)[lane];
-                        } else if (lane < 16 + CT) {
-                            const int c = lane - 16;
-                            float f = 0.0f;
-                            if (cbase + c < P.C) {
-                                if (MODE == MODE_FEATURES) f = features[a * P.C + cbase + c];
-                                else if (MODE == MODE_TYPES) f = (rec[a].type == cbase + c) ? 1.0f : 0.0f;
-                                else f = 1.0f;
-                            }
-                            v[u] = __float_as_uint(f);
-                        }
-                    }
+                    if (j < n && stager) v[u] = rows[(size_t)(a0 + list[c0 + j]) * (size_t)P.row_words + lane_word];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int j = j0 + u * NW;
-                    if (j < n && lane < 16 + CT) reinterpret_cast<unsigned *>(un + (size_t)j * STRIDE)[lane] = v[u];
+                    if (j < n && stager) un[j * SW + lane] = v[u];
                 }
             }
             __syncthreads();
+            MVX_STAMP(3)
 
             // ---- 3. walk the candidates that touch this wave's sub-tile ------------------------------
             for (int jb = 0; jb < ((P.ablate & 1) ? 0 : n); jb += 64) {
@@ -501,60 +533,56 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
                 bool ok = false;
                 if (j < n) {
                     const unsigned zr = zr_l[c0 + j];
-                    ok = ((int)(zr & 0xffff) <= zhi_w) && ((int)(zr >> 16) >= zlo_w);
+                    ok = ((int)((zr >> 16) & 0xff) <= zt_w) && ((int)(zr >> 24) >= zt_w);
                 }
                 unsigned long long mask = __ballot(ok);
                 while (mask) {
                     const int jj = jb + __builtin_ctzll(mask);
                     mask &= mask - 1;
-                    const char *r = un + (size_t)jj * STRIDE;
-                    const double2 Pxy = *reinterpret_cast<const double2 *>(r);      // px, py
-                    const double2 PzT = *reinterpret_cast<const double2 *>(r + 16); // pz, T
-                    const uint4 q = *reinterpret_cast<const uint4 *>(r + 32);       // k, type, xr, yr
+                    const unsigned *r = un + jj * SW;
+                    const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
+                    const double2 PzT = *reinterpret_cast<const double2 *>(r + 4); // pz, T
+                    const uint4 q = *reinterpret_cast<const uint4 *>(r + 8);       // k, type, xr, yr
                     const double dx = Pxy.x - gx, dy = Pxy.y - gy, dz = PzT.x - gz;
                     const double d2 = (dx * dx + dy * dy) + dz * dz; // cdist order, no fma
                     bool hit = d2 <= PzT.y;
                     if (LANE_RANGE) {
-                        const unsigned zr = *reinterpret_cast<const unsigned *>(r + 48);
+                        const unsigned zr = r[12];
                         hit = hit && (ix >= (int)(q.z & 0xffff)) && (ix <= (int)(q.z >> 16)) &&
                               (iy >= (int)(q.w & 0xffff)) && (iy <= (int)(q.w >> 16)) && (iz >= (int)(zr & 0xffff)) &&
                               (iz <= (int)(zr >> 16));
                     }
                     const float d2f = (float)d2;
-                    const float *f = reinterpret_cast<const float *>(r + 64);
+                    const float *f = reinterpret_cast<const float *>(r + 16);
                     float val = 0.0f;
-                    if (VARIANT != 2) {
-                        const float e = GAUSS ? __builtin_amdgcn_exp2f(__uint_as_float(q.x) * d2f) : 1.0f;
-                        val = hit ? e : 0.0f;
+                    if (!CHANWISE) {
+                        const float ev = GAUSS ? __builtin_amdgcn_exp2f(__uint_as_float(q.x) * d2f) : 1.0f;
+                        val = hit ? ev : 0.0f;
                     }
-                    if constexpr (CT == 1) {
-                        float vc = val;
-                        if (VARIANT == 2) {
-                            const float e = GAUSS ? __builtin_amdgcn_exp2f(kc[cbase] * d2f) : 1.0f;
-                            vc = (hit && d2 <= Tc[cbase]) ? e : 0.0f;
+                    if constexpr (CHANWISE) {
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) {
+                            const int ch = (cc * 32 + c < P.C) ? cc * 32 + c : P.C - 1;
+                            const float ev = GAUSS ? __builtin_amdgcn_exp2f(kc[ch] * d2f) : 1.0f;
+                            const float vc = (hit && d2 <= Tc[ch]) ? ev : 0.0f;
+                            if (c & 1) acc[c / 2].y = fmaf(vc, f[c], acc[c / 2].y);
+                            else acc[c / 2].x = fmaf(vc, f[c], acc[c / 2].x);
                         }
-                        acc[0].x = fmaf(vc, f[0], acc[0].x);
-                    } else if constexpr (VARIANT != 2) {
+                    } else if constexpr (CT == 1) {
+                        acc[0].x = fmaf(val, f[0], acc[0].x);
+                    } else {
                         const float2v v2 = (float2v){val, val};
 #pragma unroll
                         for (int c = 0; c < CT / 2; ++c) {
                             const float2v f2 = *reinterpret_cast<const float2v *>(f + 2 * c);
                             acc[c] = __builtin_elementwise_fma(v2, f2, acc[c]);
                         }
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < CT; ++c) {
-                            const int ch = (cbase + c < P.C) ? cbase + c : P.C - 1;
-                            const float e = GAUSS ? __builtin_amdgcn_exp2f(kc[ch] * d2f) : 1.0f;
-                            const float vc = (hit && d2 <= Tc[ch]) ? e : 0.0f;
-                            if (c & 1) acc[c / 2].y = fmaf(vc, f[c], acc[c / 2].y);
-                            else acc[c / 2].x = fmaf(vc, f[c], acc[c / 2].x);
-                        }
                     }
                 }
             }
-            __syncthreads(); // candidates consumed: the union region / list may be rewritten
+            MVX_STAMP(4)
         }
+        if (base + LCAP < nx) __syncthreads(); // another round will overwrite the list / candidate rows
     }
 
     // ---- 4. write-out ----------------------------------------------------------------------------
@@ -565,29 +593,33 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
     const int zq = z0 + 4 * q;
     const int sxx = (rfirst >> 2) & 3, syy = rfirst & 3, cfirst = rfirst >> 4;
     const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
+    const int cbase = cc * 32;
     float *dst0 = out + ((size_t)b * P.C + cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
     if (!any_candidate) {
         // empty slab: pure zero fill with the same addressing (no LDS round trip)
         if (vox_ok) {
-#pragma unroll 4
-            for (int c = cfirst; c < CT; c += 4) {
-                if (cbase + c >= P.C) break;
-                float *dst = dst0 + (size_t)(c - cfirst) * D3;
-                if (P.vec_store) {
-                    *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
-                } else {
-                    for (int e = 0; e < 4; ++e)
-                        if (zq + e < D) dst[e] = 0.0f;
+#pragma unroll
+            for (int p = 0; p < (CT + 3) / 4; ++p) {
+                const int c = cfirst + 4 * p;
+                if (c < CT && cbase + c < P.C) {
+                    float *dst = dst0 + (size_t)(4 * p) * D3;
+                    if (P.vec_store) {
+                        store_f4(dst, make_float4(0.f, 0.f, 0.f, 0.f), P.store_kind);
+                    } else {
+                        for (int k = 0; k < 4; ++k)
+                            if (zq + k < D) dst[k] = 0.0f;
+                    }
                 }
             }
         }
+        MVX_STAMP(7)
         return;
     }
     const int col = 4 * wave + lz;
     const int rxy = lx * 4 + ly;
 #pragma unroll
     for (int rd = 0; rd < NROUND; ++rd) {
-        if (rd > 0) __syncthreads(); // previous round fully read
+        __syncthreads(); // candidate rows (round 0) / previous tile (later rounds) fully consumed
 #pragma unroll
         for (int c = 0; c < CR; ++c) {
             const int cg = rd * CR + c;
@@ -595,65 +627,63 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
             tile[(c * 16 + rxy) * RS + col] = v;
         }
         __syncthreads();
+        if (rd == 0) { MVX_STAMP(5) }
         if (vox_ok) {
 #pragma unroll
             for (int p = 0; p < (CR + 3) / 4; ++p) {
                 const int c = cfirst + 4 * p; // channel inside the round
-                if (c >= CR || cbase + rd * CR + c >= P.C) break;
-                const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 64 * p) * RS + 4 * q);
-                float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
-                if (P.vec_store) {
-                    *reinterpret_cast<float4 *>(dst) = v;
-                } else {
-                    const float e4[4] = {v.x, v.y, v.z, v.w};
-                    for (int e = 0; e < 4; ++e)
-                        if (zq + e < D) dst[e] = e4[e];
+                if (c < CR && cbase + rd * CR + c < P.C) {
+                    const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 64 * p) * RS + 4 * q);
+                    float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
+                    if (P.ablate & 4) {
+                        if (v.x == 123.456f) dst[0] = v.y; // timing experiment: no stores
+                    } else if (P.vec_store) {
+                        store_f4(dst, v, P.store_kind);
+                    } else {
+                        const float e4[4] = {v.x, v.y, v.z, v.w};
+                        for (int k = 0; k < 4; ++k)
+                            if (zq + k < D) dst[k] = e4[k];
+                    }
                 }
             }
         }
     }
+    MVX_STAMP(7)
+#undef MVX_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------------
 struct KernelKey {
-    int ct, mode;
-    bool gauss;
-    int variant;
-    bool lane_range;
+    int ct;
+    bool gauss, chanwise, lane_range;
     int maxt;
 };
 
-// Calls fn.template operator()<CT, MODE, GAUSS, VARIANT, LANE_RANGE, MAXT>() for the instantiation `k` names.
+// Calls fn.template operator()<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>() for the instantiation `k` names.
 template <typename Fn>
 static hipError_t for_kernel(const KernelKey &k, Fn &&fn) {
-#define MVX_CASE(CT_, MODE_, G_, V_, LR_, MT_)                                                               \
-    if (k.ct == CT_ && k.mode == MODE_ && k.gauss == G_ && k.variant == V_ && k.lane_range == LR_ && k.maxt == MT_) \
-        return fn.template operator()<CT_, MODE_, G_, V_, LR_, MT_>();
-#define MVX_CASES_GL(CT_, MODE_, V_, MT_)     \
-    MVX_CASE(CT_, MODE_, true, V_, false, MT_)  \
-    MVX_CASE(CT_, MODE_, false, V_, false, MT_) \
-    MVX_CASE(CT_, MODE_, true, V_, true, MT_)   \
-    MVX_CASE(CT_, MODE_, false, V_, true, MT_)
-#define MVX_CASES_CT(CT_, MT_)                      \
-    MVX_CASES_GL(CT_, MODE_FEATURES, 0, MT_)        \
-    MVX_CASES_GL(CT_, MODE_FEATURES, 1, MT_)        \
-    MVX_CASES_GL(CT_, MODE_TYPES, 0, MT_)           \
-    MVX_CASE(CT_, MODE_FEATURES, true, 2, true, MT_)  \
-    MVX_CASE(CT_, MODE_FEATURES, false, 2, true, MT_)
-#define MVX_CASES_MT(MT_)    \
-    MVX_CASES_CT(1, MT_)     \
-    MVX_CASES_CT(4, MT_)     \
-    MVX_CASES_CT(8, MT_)     \
-    MVX_CASES_CT(16, MT_)    \
-    MVX_CASES_CT(32, MT_)    \
-    MVX_CASES_GL(1, MODE_SINGLE, 0, MT_)
+#define MVX_CASE(CT_, G_, CW_, LR_, MT_) \
+    if (k.ct == CT_ && k.gauss == G_ && k.chanwise == CW_ && k.lane_range == LR_ && k.maxt == MT_) \
+        return fn.template operator()<CT_, G_, CW_, LR_, MT_>();
+#define MVX_CASES_CT(CT_, MT_)             \
+    MVX_CASE(CT_, true, false, false, MT_)   \
+    MVX_CASE(CT_, false, false, false, MT_)  \
+    MVX_CASE(CT_, true, false, true, MT_)    \
+    MVX_CASE(CT_, false, false, true, MT_)   \
+    MVX_CASE(CT_, true, true, true, MT_)     \
+    MVX_CASE(CT_, false, true, true, MT_)
+#define MVX_CASES_MT(MT_) \
+    MVX_CASES_CT(1, MT_)  \
+    MVX_CASES_CT(4, MT_)  \
+    MVX_CASES_CT(8, MT_)  \
+    MVX_CASES_CT(16, MT_) \
+    MVX_CASES_CT(32, MT_)
     MVX_CASES_MT(512)
     MVX_CASES_MT(1024)
 #undef MVX_CASES_MT
 #undef MVX_CASES_CT
-#undef MVX_CASES_GL
 #undef MVX_CASE
     return hipErrorInvalidValue;
 }
@@ -661,34 +691,31 @@ static hipError_t for_kernel(const KernelKey &k, Fn &&fn) {
 struct LaunchFn {
     const VoxArgs &a;
     hipStream_t s;
-    template <int CT, int MODE, bool GAUSS, int VARIANT, bool LANE_RANGE, int MAXT>
+    template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
     hipError_t operator()() const {
-        const long long blocks = (long long)a.p.B * a.p.ncc * a.p.nsx * a.p.nsx * a.p.nzc;
-        if (blocks <= 0) return hipSuccess;
-        if (blocks > 0x7fffffffLL) return hipErrorInvalidConfiguration;
-        const size_t lds = voxelize_lds_bytes(CT, a.p.NW, nullptr);
+        const VoxParams &p = a.p;
+        if (p.B <= 0) return hipSuccess;
+        if ((long long)p.nsx * p.nsx > 65535 || (long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
+        const size_t lds = voxelize_lds_bytes(CT, p.NW);
         if (lds > 64 * 1024) { // above the default dynamic-LDS limit: raise it once per instantiation
             static size_t raised = 0;
             if (lds > raised) {
                 hipError_t e = hipFuncSetAttribute(
-                    reinterpret_cast<const void *>(&voxelize_kernel<CT, MODE, GAUSS, VARIANT, LANE_RANGE, MAXT>),
+                    reinterpret_cast<const void *>(&voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>),
                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return e;
                 raised = lds;
             }
         }
-        hipLaunchKernelGGL((voxelize_kernel<CT, MODE, GAUSS, VARIANT, LANE_RANGE, MAXT>), dim3((unsigned)blocks),
-                           dim3(a.p.NW * 64), lds, s, a.rec, a.features, a.xlist, a.xcount, a.offsets, a.Tc, a.kc,
-                           a.out, a.p);
+        hipLaunchKernelGGL((voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>),
+                           dim3((unsigned)p.nzc, (unsigned)(p.nsx * p.nsx), (unsigned)(p.B * p.ncc)), dim3(p.NW * 64), lds, s,
+                           a.rows, a.xlist, a.xcount, a.offsets, a.Tc, a.kc, a.out, a.p);
         return hipGetLastError();
     }
 };
 
 hipError_t launch_voxelize(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {
-    int variant = 0;
-    if (chanwise) variant = 2;
-    else if (a.p.mode == MODE_FEATURES && a.p.C % ct != 0) variant = 1;
-    KernelKey k{ct, a.p.mode, gauss, variant, variant == 2 ? true : lane_range, a.p.NW <= 8 ? 512 : 1024};
+    KernelKey k{ct, gauss, chanwise, chanwise ? true : lane_range, a.p.NW <= 8 ? 512 : 1024};
     return for_kernel(k, LaunchFn{a, s});
 }
 
