@@ -17,15 +17,7 @@ buf = np.zeros((nb, 8), dtype=np.uint64)
 n = C.c_int64(0)
 _lib.check(vox._lib.mvx_debug_read_stamps(vox._handle, buf.ctypes.data, nb, C.byref(n)))
 s = buf[: n.value].astype(np.int64)
-ok = (s[:, [0,1,2,3,4,5,7]] > 0).all(axis=1)
-s = s[ok]
-print("blocks with candidates:", len(s), "of", n.value)
-names = ["start->nx,a0 ready", "->scan done", "->staged", "->walk done(w0)", "->tile0 ready", "->end"]
-idx = [0,1,2,3,4,5,7]
-for k in range(6):
-    d = s[:, idx[k + 1]] - s[:, idx[k]]
-    print(f"{names[k]:28s} mean {d.mean():9.0f}  p50 {np.median(d):9.0f}  p90 {np.percentile(d,90):9.0f} (memtime ticks = 100MHz? or shader clk)")
-tot = s[:, 7] - s[:, 0]
-print("total", tot.mean(), np.median(tot))
-span = s[:, 7].max() - s[:, 0].min()
-print("kernel span ticks", span)
+print("blocks", n.value)
+for a, b_, name in [(0,1,"start->xlist in LDS"),(1,2,"->first scan+prefetch issued"),(2,3,"->slab0 walk done"),(3,4,"->slab0 written"),(4,7,"->end (remaining slabs)"),(0,7,"total")]:
+    d = s[:, b_] - s[:, a]
+    print(f"{name:30s} mean {d.mean():9.0f} p50 {np.median(d):9.0f} p90 {np.percentile(d,90):9.0f}")
