@@ -65,9 +65,11 @@ struct mvx_handle {
     bool profiling = false;
     int force_nw = 0;
     int ablate = 0;
-    int force_g = 0;
-    DevBuf overflow;
+    int want_stamps = 0;
+    size_t stamp_blocks = 0;
+    DevBuf stamps;
     int row_bytes = 64;
+    int xcd_swap = 0; // measured slower on cfg-2 (0.61 vs 0.56 ms): kept as an experiment knob (MVX_XCD_SWAP=1)
     int store_kind = 1; // nt: measured 0.69 -> 0.54 ms on cfg-2 (output lines do not displace the re-read inputs in L2)
 };
 
@@ -301,7 +303,6 @@ int run(mvx_handle *h, const RunArgs &r) {
     VoxArgs va;
     va.rows = reinterpret_cast<const unsigned *>(h->rec.p);
     va.p.row_words = row_words;
-    va.offsets = d_off;
     va.Tc = d_Tc;
     va.kc = d_kc;
     va.out = d_out;
@@ -326,38 +327,30 @@ int run(mvx_handle *h, const RunArgs &r) {
         nzc = (nz4 + NW - 1) / NW;
     }
     va.p.nsx = nz4;
+    va.p.nsx_inv = (uint32_t)((0x100000000ull + (uint64_t)nz4 - 1) / (uint64_t)nz4);
     va.p.nzc = nzc;
+    va.p.nzc_inv = (nzc == 1) ? 0xffffffffu : (uint32_t)((0x100000000ull + (uint64_t)nzc - 1) / (uint64_t)nzc);
+    va.p.xcd_swap = (h->xcd_swap && ((long long)nzc * nz4 * nz4) % 8 == 0) ? 1 : 0;
     va.p.NW = NW;
     // x-slab binning (ordered lists per (molecule, x-slab), fixed-stride regions)
     int64_t nmax = 1;
     for (int b = 0; b < r.B; ++b) nmax = std::max<int64_t>(nmax, r.offsets[b + 1] - r.offsets[b]);
-    if ((rc = ensure(h->xlist, (size_t)r.B * nz4 * (size_t)nmax * sizeof(uint2)))) return rc;
-    if ((rc = ensure(h->xcount, (size_t)r.B * nz4 * sizeof(int)))) return rc;
-    HIP_TRY(launch_xbin(pa.bbox, d_off, r.B, nz4, (int32_t)nmax, reinterpret_cast<uint2 *>(h->xlist.p),
-                        reinterpret_cast<int *>(h->xcount.p), s));
-    va.p.xstride = (int32_t)nmax;
+    const int64_t xstride = nmax + 2; // two header entries per list
+    if ((rc = ensure(h->xlist, (size_t)r.B * nz4 * (size_t)xstride * sizeof(uint2)))) return rc;
+    HIP_TRY(launch_xbin(pa.bbox, d_off, r.B, nz4, (int32_t)xstride, reinterpret_cast<uint2 *>(h->xlist.p), s));
+    va.p.xstride = (int32_t)xstride;
     va.xlist = reinterpret_cast<const uint2 *>(h->xlist.p);
-    va.xcount = reinterpret_cast<const int *>(h->xcount.p);
     va.p.ncc = ncc;
-    va.p.dcap = generic_dcap(ct, NW);
-    {
-        // y-slabs per workgroup: long enough to amortise the prologue and keep the prefetch pipeline primed,
-        // short enough that the grid still holds several workgroups per CU (256 CUs x 3 resident x ~4 rounds)
-        const long long slabs = (long long)r.B * ncc * nz4 * nz4 * nzc;
-        int G = (int)std::min<long long>(nz4, std::max<long long>(1, slabs / (256 * 3 * 4)));
-        if (h->force_g > 0) G = std::min(h->force_g, nz4);
-        va.p.G = G;
-        va.p.ngrp = (nz4 + G - 1) / G;
-        va.p.ngrp_inv = (uint32_t)(((1u << 24) + (uint32_t)va.p.ngrp - 1u) / (uint32_t)va.p.ngrp);
-    }
+    va.p.dcap = voxelize_dcap(ct, NW);
     va.p.vec_store = (D % 4 == 0) ? 1 : 0;
     va.p.ablate = h->ablate;
-    {
-        const size_t nslabs = (size_t)r.B * ncc * nz4 * nz4 * nzc;
-        if (nslabs + 1 > (size_t)0x7fffffff) return fail(MVX_ERR_INVALID, "batch too large for one call");
-        if ((rc = ensure(h->overflow, (nslabs + 1) * sizeof(int)))) return rc;
-        HIP_TRY(hipMemsetAsync(h->overflow.p, 0, sizeof(int), s));
-        va.overflow = reinterpret_cast<int *>(h->overflow.p);
+    va.p.stamps = nullptr;
+    if (h->want_stamps) {
+        const size_t nblk = (size_t)r.B * ncc * nz4 * nz4 * nzc;
+        if ((rc = ensure(h->stamps, nblk * 8 * sizeof(unsigned long long)))) return rc;
+        HIP_TRY(hipMemsetAsync(h->stamps.p, 0, nblk * 8 * sizeof(unsigned long long), s));
+        va.p.stamps = reinterpret_cast<unsigned long long *>(h->stamps.p);
+        h->stamp_blocks = nblk;
     }
     va.p.store_kind = h->store_kind;
     // a 4^3 sub-tile lies inside one reference block when 4 | blockdim (or there is a single block):
@@ -426,8 +419,9 @@ int mvx_create(const mvx_config *cfg, mvx_handle **out) {
     make_geom(h);
     if (const char *env = std::getenv("MVX_NW")) h->force_nw = std::atoi(env);
     if (const char *env = std::getenv("MVX_ABLATE")) h->ablate = std::atoi(env);
-    if (const char *env = std::getenv("MVX_G")) h->force_g = std::atoi(env);
+    if (const char *env = std::getenv("MVX_STAMPS")) h->want_stamps = std::atoi(env);
     if (const char *env = std::getenv("MVX_STORE")) h->store_kind = std::atoi(env);
+    if (const char *env = std::getenv("MVX_XCD_SWAP")) h->xcd_swap = std::atoi(env);
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) {
         delete h;
@@ -445,7 +439,7 @@ int mvx_destroy(mvx_handle *h) {
     if (!h) return MVX_OK;
     DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&h->rec, &h->bbox, &h->xlist, &h->xcount, &h->overflow, &h->meta, &h->aux, &h->in_coords, &h->in_chan, &h->in_radii, &h->out_stage};
+    DevBuf *bufs[] = {&h->rec, &h->bbox, &h->xlist, &h->xcount, &h->meta, &h->aux, &h->in_coords, &h->in_chan, &h->in_radii, &h->out_stage};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (PinnedSlot &s : h->slots) {
@@ -594,13 +588,13 @@ int mvx_last_kernel_ms(mvx_handle *h, float *ms) {
     return MVX_OK;
 }
 
-int mvx_debug_overflow_count(mvx_handle *h, int32_t *count) {
-    if (!h || !count) return fail(MVX_ERR_INVALID, "bad argument");
-    *count = 0;
-    if (!h->overflow.p) return MVX_OK;
+int mvx_debug_read_stamps(mvx_handle *h, void *host_dst, int64_t max_blocks, int64_t *blocks) {
+    if (!h || !host_dst || !blocks) return fail(MVX_ERR_INVALID, "bad argument");
     DeviceGuard guard(h->device);
+    const size_t n = std::min<size_t>(h->stamp_blocks, (size_t)max_blocks);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(count, h->overflow.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (n) HIP_TRY(hipMemcpy(host_dst, h->stamps.p, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    *blocks = (int64_t)n;
     return MVX_OK;
 }
 

@@ -56,26 +56,24 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
     double res, half;
     int32_t D, C, B;
     int32_t nsx, nzc, ncc; // slabs per x/y axis, z chunks, channel chunks
-    int32_t G, ngrp;       // y-slabs walked by one workgroup, groups per x-slab = ceil(nsx / G)
-    uint32_t ngrp_inv;     // ceil(2^24 / ngrp): blockIdx.y / ngrp without an integer division
+    uint32_t nsx_inv, nzc_inv; // ceil(2^32 / d): n / d == __umulhi(n, inv) for the slab ids used here (n * d < 2^32)
+    int32_t xcd_swap;      // 1: swap the low 3 bits of slab id and molecule id (XCD-affine molecules; experiment knob MVX_XCD_SWAP=1, default off)
     int32_t NW;            // waves per workgroup = 4^3 sub-tiles per slab
     int32_t row_words;     // words per atom row (16 + Cpad)
-    int32_t dcap;          // candidate rows staged per round by the generic kernel
+    int32_t dcap;          // candidate rows staged per round
     int32_t xstride;       // entries per (molecule, x-slab) list region = largest molecule of the batch
     int32_t vec_store;     // D % 4 == 0 and out 16-B aligned
     int32_t store_kind;    // 0 plain, 1 nt, 2 sc1 (MVX_STORE)
     int32_t ablate;        // timing experiments only (MVX_ABLATE): 1 no walk, 2 every slab empty, 4 no stores
+    unsigned long long *stamps; // diagnostic builds only (MVX_STAMPS=1): 8 time stamps per workgroup, else null
 };
 
 struct VoxArgs {
     const unsigned *rows;  // per-atom rows (record + channel weights)
     const uint2 *xlist;    // x-slab lists (xbin_kernel)
-    const int *xcount;     // their lengths, [B * nsx]
-    const int64_t *offsets;
     const double *Tc;      // channel-wise features: per-channel d2 thresholds
     const float *kc;       //                        per-channel gaussian coefficients
     float *out;            // (B, C, D, D, D)
-    int *overflow;         // [0] = count (zeroed per call), [1..] slab ids left to the generic kernel
     VoxParams p;
 };
 
@@ -84,13 +82,13 @@ hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float
                            double *Tc, float *kc, hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
 hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, int32_t xstride, uint2 *xlist,
-                       int *xcount, hipStream_t s);
+                       hipStream_t s);
 hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf_dev, double *out, hipStream_t s);
 // ct: channels per thread (1, 4, 8, 16, 32); lane_range: per-lane index-range check needed
 hipError_t launch_voxelize(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
 hipError_t configure_kernels(); // raises the dynamic-LDS limit of every instantiation
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW);
-int32_t generic_dcap(int32_t ct, int32_t NW);
+int32_t voxelize_dcap(int32_t ct, int32_t NW);
 hipError_t launch_pack_channels(float *rows, int32_t row_words, int32_t Cpad, int32_t C, int32_t mode,
                                 const float *features, const int32_t *types, int64_t total, hipStream_t s);
 

@@ -313,9 +313,10 @@ hipError_t launch_pack_channels(float *rows, int32_t row_words, int32_t Cpad, in
 // (b, sx) lives at xlist[(b*nsx + sx) * xstride] (xstride = largest molecule of the batch), its length in
 // xcount[b*nsx+sx].
 constexpr uint32_t EMPTY_ENTRY = 0x00ff00ffu; // y lo = z lo = 255, hi = 0: matches no slab
+constexpr int XL_HEADER = 2; // entry 0 = {count, EMPTY}, entry 1 = {first atom of the molecule, EMPTY}; candidates follow
 
 __global__ void __launch_bounds__(64) xbin_kernel(const uint4 *bbox, const int64_t *offsets, int nsx, int xstride,
-                                                  uint2 *xlist, int *xcount) {
+                                                  uint2 *xlist) {
     const int b = blockIdx.x / nsx, sx = blockIdx.x % nsx;
     const int lane = threadIdx.x;
     const int64_t a0 = offsets[b], a1 = offsets[b + 1];
@@ -335,48 +336,40 @@ __global__ void __launch_bounds__(64) xbin_kernel(const uint4 *bbox, const int64
             const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
             const unsigned packed = ((bb.y & 0xffff) >> 2) | (((bb.y >> 16) >> 2) << 8) | (((bb.z & 0xffff) >> 2) << 16) |
                                     (((bb.z >> 16) >> 2) << 24);
-            dst[count + below] = make_uint2((unsigned)(a - a0), packed);
+            dst[XL_HEADER + count + below] = make_uint2((unsigned)(a - a0), packed);
         }
         count += __popcll(mask);
     }
-    if (lane == 0) xcount[blockIdx.x] = count;
+    // the header travels with the first entries: the voxelize kernel needs no separate (dependent) scalar loads
+    if (lane == 0) dst[0] = make_uint2((unsigned)count, EMPTY_ENTRY);
+    if (lane == 1) dst[1] = make_uint2((unsigned)(a0 & 0xffffffffll), EMPTY_ENTRY);
 }
 
 hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, int32_t xstride, uint2 *xlist,
-                       int *xcount, hipStream_t s) {
+                       hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(64), 0, s, bbox, offsets, nsx, xstride, xlist,
-                       xcount);
+    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(64), 0, s, bbox, offsets, nsx, xstride, xlist);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
 // voxelize
 // ------------------------------------------------------------------------------------------------
-// Work decomposition shared by both kernels: one slab = 4 x 4 x (4*NW) voxels = NW waves, one 4^3 sub-tile per
-// wave, one voxel per lane, CT channel accumulators per lane in registers. Every output byte is written exactly
-// once (zeros included) with 16-B/lane non-temporal stores in whole-row runs; no atomics, no memset, no MFMA.
-//
-// voxelize_kernel (fast path). One workgroup walks G consecutive slabs (same molecule, x-slab and z chunk,
-// sy = sy0 .. sy0+G-1). grid = (z chunk, sx * ngrp + group, molecule * ncc + channel chunk). Loads are slow while
-// the chip is saturated with output stores (measured 2-4 us per dependent load), so the slab loop is software
-// pipelined and no load sits on a slab's critical path once the pipeline is primed:
-//   prologue  the (molecule, x-slab) list (<= XCAP packed 8-B entries) is copied to LDS once per workgroup;
-//   per slab  A. candidate rows prefetched into registers during the previous slab are written to LDS
-//             B. one wave (rotating) compacts the LDS x-list against the NEXT slab's y/z box (ballot + running
-//                count: atom order kept) while
-//             C. every wave walks the candidates whose z range touches its sub-tile: broadcast LDS reads, fp64 d2
-//                in cdist order, compare with T, exp2, packed FMAs
-//             E. loads of the next slab's rows are issued (64-B record + CT channel weights, one coalesced load
-//                per candidate, 8 per wave) and stay in flight during
-//             F. write-out: accumulators -> LDS tile (CR = min(CT,16) channels per round) -> stores.
-//             Empty slabs skip the LDS round trip.
-//   A slab with more than 8*NW candidates, or an x-list longer than XCAP, is not computed here: its id is appended
-//   to an overflow list and voxelize_generic_kernel produces it (dense clusters; rare).
-// LDS map (dynamic, 16-B aligned):
-//   [0, 8*XCAP) uint2 xl[] | 2 x { int list[XCAP] ; uint32 zr[XCAP] } | int nl[2] (+pad) |
-//   union { 8*NW x SW words of candidate rows ; (CR*16 rows) x RS floats out tile, RS = 4*NW + pad ((RS/4) odd) }
-constexpr int XCAP = 512;
+// One workgroup = one slab of 4 x 4 x (4*NW) voxels; one wave = one 4^3 sub-tile; one lane = one voxel with
+// CT channel accumulators in registers. grid = (z chunk, sx*nsx + sy, molecule*ncc + channel chunk).
+//   1. scan (wave 0 only, the others wait at the barrier): up to 8 entries per lane of the slab's x-list are
+//      loaded at once (the list sits at a fixed stride, so the loads are in flight while the list length is
+//      still being fetched) and tested against the slab's y/z box; matches are compacted in atom order (ballot +
+//      running count, no cross-wave exchange) into an LDS list;
+//   2. stage: wave w copies the rows of candidates w, w+NW, ... (64-B record + CT channel weights; one coalesced
+//      load each, up to 8 in flight) into LDS; one barrier;
+//   3. walk: each wave picks the candidates whose z range touches its sub-tile (lane-parallel filter + ballot)
+//      and processes them: broadcast LDS reads, fp64 d2 in cdist order, compare with T, exp2, packed FMAs;
+//   4. write-out: accumulators -> LDS tile (CR = min(CT,16) channels per round) -> non-temporal 16-B/lane
+//      stores in whole-row runs. Empty slabs skip the LDS round trip.
+// LDS map (dynamic, 16-B aligned), LCAP = 64 * min(NW, 8):
+//   [0, 4*LCAP) int list[] | [4*LCAP, 8*LCAP) uint32 zr[] | [8*LCAP, +16) int nlist |
+//   union { LCAP x SW words of candidate rows ; (CR*16 rows) x RS floats out tile, RS = 4*NW + pad ((RS/4) odd) }
 
 // 16-B output store. kind 0: plain (line stays in the XCD's L2); 1: nt; 2: sc1 (write-through). Output bytes are
 // written once and never re-read here; nt keeps them from displacing the re-read inputs (0.69 -> 0.54 ms, cfg-2).
@@ -394,85 +387,261 @@ __device__ __forceinline__ void store_f4(float *dst, const float4 v, int kind) {
 
 __host__ __device__ __forceinline__ int row_stride_floats(int NW) { return 4 * NW + ((NW & 1) ? 8 : 4); }
 __host__ __device__ __forceinline__ int cand_stride_words(int ct) { return 16 + (ct < 4 ? 4 : ct); }
-constexpr int LDS_FIXED = 8 * XCAP + 2 * 8 * XCAP + 16;
+
+// candidate rows staged per round: what fits in the out tile's bytes, at least 64, at most the list capacity
+int32_t voxelize_dcap(int32_t ct, int32_t NW) {
+    const int cr = ct < 16 ? ct : 16;
+    const int lcap = 64 * (NW < 8 ? NW : 8);
+    const size_t tile = (size_t)cr * 16 * row_stride_floats(NW) * 4;
+    int cap = (int)(tile / ((size_t)cand_stride_words(ct) * 4));
+    if (cap < 64) cap = 64;
+    if (cap > lcap) cap = lcap;
+    return cap;
+}
 
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW) {
     const int cr = ct < 16 ? ct : 16;
+    const int lcap = 64 * (NW < 8 ? NW : 8);
     const size_t tile = (size_t)cr * 16 * row_stride_floats(NW) * 4;
-    const size_t cand = (size_t)8 * NW * cand_stride_words(ct) * 4;
-    return (size_t)LDS_FIXED + (tile > cand ? tile : cand);
+    const size_t cand = (size_t)voxelize_dcap(ct, NW) * cand_stride_words(ct) * 4;
+    return (size_t)8 * lcap + 16 + (tile > cand ? tile : cand);
 }
 
-// The candidate walk of one wave over rows [0, n) staged in LDS (`un`, SW words each; z ranges in zr[]).
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
-__device__ __forceinline__ void walk_candidates(float2v (&acc)[(CT + 1) / 2], const unsigned *un, const unsigned *zr, int n,
-                                                int lane, int zt_w, double gx, double gy, double gz, int ix, int iy,
-                                                int iz, int cbase, int C, const double *__restrict__ Tc,
-                                                const float *__restrict__ kc) {
-    constexpr int SW = 16 + (CT < 4 ? 4 : CT);
-    for (int jb = 0; jb < n; jb += 64) {
-        const int j = jb + lane;
-        bool ok = false;
-        if (j < n) {
-            const unsigned pk = zr[j];
-            ok = ((int)((pk >> 16) & 0xff) <= zt_w) && ((int)(pk >> 24) >= zt_w);
-        }
-        unsigned long long mask = __ballot(ok);
-        while (mask) {
-            const int jj = jb + __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const unsigned *r = un + jj * SW;
-            const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
-            const double2 PzT = *reinterpret_cast<const double2 *>(r + 4); // pz, T
-            const uint4 qq = *reinterpret_cast<const uint4 *>(r + 8);      // k, type, xr, yr
-            const double dx = Pxy.x - gx, dy = Pxy.y - gy, dz = PzT.x - gz;
-            const double d2 = (dx * dx + dy * dy) + dz * dz; // cdist order, no fma
-            bool hit = d2 <= PzT.y;
-            if (LANE_RANGE) {
-                const unsigned zrr = r[12];
-                hit = hit && (ix >= (int)(qq.z & 0xffff)) && (ix <= (int)(qq.z >> 16)) && (iy >= (int)(qq.w & 0xffff)) &&
-                      (iy <= (int)(qq.w >> 16)) && (iz >= (int)(zrr & 0xffff)) && (iz <= (int)(zrr >> 16));
-            }
-            const float d2f = (float)d2;
-            const float *f = reinterpret_cast<const float *>(r + 16);
-            float val = 0.0f;
-            if (!CHANWISE) {
-                const float ev = GAUSS ? __builtin_amdgcn_exp2f(__uint_as_float(qq.x) * d2f) : 1.0f;
-                val = hit ? ev : 0.0f;
-            }
-            if constexpr (CHANWISE) {
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    const int ch = (cbase + c < C) ? cbase + c : C - 1;
-                    const float ev = GAUSS ? __builtin_amdgcn_exp2f(kc[ch] * d2f) : 1.0f;
-                    const float vc = (hit && d2 <= Tc[ch]) ? ev : 0.0f;
-                    if (c & 1) acc[c / 2].y = fmaf(vc, f[c], acc[c / 2].y);
-                    else acc[c / 2].x = fmaf(vc, f[c], acc[c / 2].x);
-                }
-            } else if constexpr (CT == 1) {
-                acc[0].x = fmaf(val, f[0], acc[0].x);
-            } else {
-                const float2v v2 = (float2v){val, val};
-#pragma unroll
-                for (int c = 0; c < CT / 2; ++c) {
-                    const float2v f2 = *reinterpret_cast<const float2v *>(f + 2 * c);
-                    acc[c] = __builtin_elementwise_fma(v2, f2, acc[c]);
-                }
-            }
-        }
-    }
-}
-
-// Write-out of one slab: accumulators -> LDS tile (rounds of CR channels) -> global. Ends WITHOUT a barrier.
-template <int CT>
-__device__ __forceinline__ void write_out(const float2v (&acc)[(CT + 1) / 2], float *tile, int RS, int rxy, int col,
-                                          int rfirst, int q, int cfirst, bool vox_ok, float *dst0, size_t D3, int cbase,
-                                          int C, int zq, int D, int vec_store, int store_kind, bool no_stores) {
-    constexpr int CR = CT < 16 ? CT : 16;
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
+__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
+    voxelize_kernel(const unsigned *__restrict__ rows, const uint2 *__restrict__ xlist,
+                    const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
+                    const VoxParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CR = CT < 16 ? CT : 16; // channels per write-out round
     constexpr int NROUND = CT / CR;
+    constexpr int SW = 16 + (CT < 4 ? 4 : CT); // LDS words per candidate (multiple of 4)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // diagnostic builds only (MVX_STAMPS): phase time stamps of thread 0 into a buffer nothing else reads
+    const size_t blk = blockIdx.x + (size_t)gridDim.x * blockIdx.y;
+#define MVX_STAMP(k) \
+    if (P.stamps && tid == 0) P.stamps[blk * 8 + (k)] = __builtin_amdgcn_s_memtime();
+    MVX_STAMP(0)
+    const int NW = P.NW;
+    const int SB = NW < 8 ? NW : 8; // x-list entries per lane and scan round
+    const int LCAP = 64 * SB;
+    const int D = P.D;
+
+    int *list = reinterpret_cast<int *>(smem);
+    unsigned *zr_l = reinterpret_cast<unsigned *>(smem + 4 * LCAP);
+    int *nlist_s = reinterpret_cast<int *>(smem + 8 * LCAP); // [0] matches of this round, [1] list length, [2] first atom
+    unsigned *un = reinterpret_cast<unsigned *>(smem + 8 * LCAP + 16);
+    float *tile = reinterpret_cast<float *>(un);
+
+    // ---- block -> (molecule * ncc + channel chunk, slab) -------------------------------------------
+    // grid = (T, Z): t = zc + nzc * (sy + nsx * sx) slab id, z = molecule * ncc + chunk. Workgroups are dealt
+    // round-robin over the 8 XCDs in linear order (block L -> XCD L % 8; observed, used for speed only: any
+    // placement gives the same result). With T % 8 == 0 the XCD is t % 8, so swapping the low three bits of t
+    // and z makes XCD k work through all slabs of molecule (z & ~7) + k: its rows and x-lists are then pulled
+    // into ONE L2 instead of eight. Bijective on z < 8 * (Z / 8); the tail keeps the identity.
+    unsigned t = blockIdx.x, z = blockIdx.y;
+    if (P.xcd_swap && z < (gridDim.y & ~7u)) {
+        const unsigned tl = t & 7u, zl = z & 7u;
+        t = (t & ~7u) | zl;
+        z = (z & ~7u) | tl;
+    }
+    const unsigned ty = (P.nzc == 1) ? t : __umulhi(t, P.nzc_inv); // t / nzc
+    const int zc = (int)(t - ty * P.nzc);
+    const int sx = (P.nsx == 1) ? (int)ty : (int)__umulhi(ty, P.nsx_inv); // ty / nsx
+    const int sy = (int)ty - sx * P.nsx;
+    int b = (int)z, cc = 0;
+    if (P.ncc > 1) {
+        b = (int)z / P.ncc;
+        cc = (int)z - b * P.ncc;
+    }
+    const int x0 = 4 * sx, y0 = 4 * sy, z0 = zc * 4 * NW;
+    const int zt_lo = zc * NW, zt_hi = zt_lo + NW - 1; // sub-tile index range of the slab along z
+    // x-list of (b, sx): fixed-stride region whose first two entries carry the list length and the molecule's
+    // first atom, so nothing here waits for a dependent scalar load
+    const uint2 *__restrict__ xl = xlist + ((size_t)b * P.nsx + sx) * (size_t)P.xstride;
+    const uint2 kEmpty = make_uint2(0u, EMPTY_ENTRY);
+    uint2 e[8];
+    if (wave == 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = u * 64 + lane;
+            e[u] = (u < SB && i < P.xstride) ? xl[i] : kEmpty;
+        }
+        // header -> LDS for the other waves (they read it after the first barrier)
+        if (lane == 0) nlist_s[1] = (P.ablate & 2) ? XL_HEADER : (int)e[0].x + XL_HEADER;
+        if (lane == 1) nlist_s[2] = (int)e[0].x;
+    }
+    MVX_STAMP(1)
+
+    // ---- this lane's voxel ---------------------------------------------------------------------
+    const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
+    const int ix = x0 + lx, iy = y0 + ly, iz = z0 + 4 * wave + lz;
+    const double gx = (double)ix * P.res - P.half; // axis[i] = i*res - width/2, numpy/voxelizer.py:41-43
+    const double gy = (double)iy * P.res - P.half;
+    const double gz = (double)iz * P.res - P.half;
+    const int zt_w = zt_lo + wave; // this wave's sub-tile index along z
+    // row word this lane stages: 0-15 record, 16.. the CT channel weights of chunk cc
+    const int lane_word = lane < 16 ? lane : lane + cc * 32;
+    const bool stager = lane < 16 + CT;
+
+    float2v acc[(CT + 1) / 2];
+#pragma unroll
+    for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
+
+    bool any_candidate = false;
+    int nx = LCAP; // entries incl. header; the real value is published with the first round's list
+    int64_t a0 = 0;
+    for (int base = 0; base < nx; base += LCAP) {
+        // ---- 1. wave 0: ordered compaction of LCAP x-list entries against the slab's y/z box ---------
+        if (wave == 0) {
+            const int nxw = (base == 0) ? __builtin_amdgcn_readlane((int)e[0].x, 0) + XL_HEADER : nx;
+            const int nxe = (P.ablate & 2) ? XL_HEADER : nxw;
+            int n = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u < SB) {
+                    const int i = base + u * 64 + lane;
+                    uint2 en = e[u];
+                    if (base > 0) en = (i < nxe) ? xl[i] : kEmpty;
+                    // packed slab ranges: y lo | y hi << 8 | z sub-tile lo << 16 | z sub-tile hi << 24
+                    // (the two header entries carry EMPTY_ENTRY and never match)
+                    const bool m = (i < nxe) && ((int)(en.y & 0xff) <= sy) && ((int)((en.y >> 8) & 0xff) >= sy) &&
+                                   ((int)((en.y >> 16) & 0xff) <= zt_hi) && ((int)(en.y >> 24) >= zt_lo);
+                    const unsigned long long mask = __ballot(m);
+                    if (m) {
+                        const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        list[pos] = (int)en.x;
+                        zr_l[pos] = en.y;
+                    }
+                    n += __popcll(mask);
+                }
+            }
+            if (lane == 0) nlist_s[0] = n;
+        }
+        __syncthreads(); // list complete
+        const int nl = nlist_s[0];
+        nx = nlist_s[1];
+        a0 = (int64_t)(unsigned)nlist_s[2];
+        MVX_STAMP(2)
+        for (int c0 = 0; c0 < nl; c0 += P.dcap) {
+            const int n = (nl - c0) < P.dcap ? (nl - c0) : P.dcap; // rows staged this round
+            if (c0 > 0) __syncthreads(); // previous round's rows consumed
+            any_candidate = true;
+            // ---- 2. stage rows: lanes 0-15 the 64-B record, lanes 16..16+CT-1 the channel weights -------
+            for (int j0 = wave; j0 < n; j0 += 8 * NW) {
+                unsigned v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u * NW;
+                    v[u] = 0u;
+                    if (j < n && stager) v[u] = rows[(size_t)(a0 + list[c0 + j]) * (size_t)P.row_words + lane_word];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u * NW;
+                    if (j < n && stager) un[j * SW + lane] = v[u];
+                }
+            }
+            __syncthreads();
+            MVX_STAMP(3)
+
+            // ---- 3. walk the candidates that touch this wave's sub-tile ------------------------------
+            for (int jb = 0; jb < ((P.ablate & 1) ? 0 : n); jb += 64) {
+                const int j = jb + lane;
+                bool ok = false;
+                if (j < n) {
+                    const unsigned zr = zr_l[c0 + j];
+                    ok = ((int)((zr >> 16) & 0xff) <= zt_w) && ((int)(zr >> 24) >= zt_w);
+                }
+                unsigned long long mask = __ballot(ok);
+                while (mask) {
+                    const int jj = jb + __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const unsigned *r = un + jj * SW;
+                    const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
+                    const double2 PzT = *reinterpret_cast<const double2 *>(r + 4); // pz, T
+                    const uint4 q = *reinterpret_cast<const uint4 *>(r + 8);       // k, type, xr, yr
+                    const double dx = Pxy.x - gx, dy = Pxy.y - gy, dz = PzT.x - gz;
+                    const double d2 = (dx * dx + dy * dy) + dz * dz; // cdist order, no fma
+                    bool hit = d2 <= PzT.y;
+                    if (LANE_RANGE) {
+                        const unsigned zr = r[12];
+                        hit = hit && (ix >= (int)(q.z & 0xffff)) && (ix <= (int)(q.z >> 16)) &&
+                              (iy >= (int)(q.w & 0xffff)) && (iy <= (int)(q.w >> 16)) && (iz >= (int)(zr & 0xffff)) &&
+                              (iz <= (int)(zr >> 16));
+                    }
+                    const float d2f = (float)d2;
+                    const float *f = reinterpret_cast<const float *>(r + 16);
+                    float val = 0.0f;
+                    if (!CHANWISE) {
+                        const float ev = GAUSS ? __builtin_amdgcn_exp2f(__uint_as_float(q.x) * d2f) : 1.0f;
+                        val = hit ? ev : 0.0f;
+                    }
+                    if constexpr (CHANWISE) {
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) {
+                            const int ch = (cc * 32 + c < P.C) ? cc * 32 + c : P.C - 1;
+                            const float ev = GAUSS ? __builtin_amdgcn_exp2f(kc[ch] * d2f) : 1.0f;
+                            const float vc = (hit && d2 <= Tc[ch]) ? ev : 0.0f;
+                            if (c & 1) acc[c / 2].y = fmaf(vc, f[c], acc[c / 2].y);
+                            else acc[c / 2].x = fmaf(vc, f[c], acc[c / 2].x);
+                        }
+                    } else if constexpr (CT == 1) {
+                        acc[0].x = fmaf(val, f[0], acc[0].x);
+                    } else {
+                        const float2v v2 = (float2v){val, val};
+#pragma unroll
+                        for (int c = 0; c < CT / 2; ++c) {
+                            const float2v f2 = *reinterpret_cast<const float2v *>(f + 2 * c);
+                            acc[c] = __builtin_elementwise_fma(v2, f2, acc[c]);
+                        }
+                    }
+                }
+            }
+            MVX_STAMP(4)
+        }
+        if (base + LCAP < nx) __syncthreads(); // another round will overwrite the list / candidate rows
+    }
+
+    // ---- 4. write-out ----------------------------------------------------------------------------
+    const int RS = row_stride_floats(NW);
+    const size_t D2 = (size_t)D * D, D3 = D2 * D;
+    const int q = tid % NW;      // float4 slot inside a row
+    const int rfirst = tid / NW; // 0..63: row of this thread in pass 0; rows advance by 64 (= 4 channels) per pass
+    const int zq = z0 + 4 * q;
+    const int sxx = (rfirst >> 2) & 3, syy = rfirst & 3, cfirst = rfirst >> 4;
+    const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
+    const int cbase = cc * 32;
+    float *dst0 = out + ((size_t)b * P.C + cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
+    if (!any_candidate) {
+        // empty slab: pure zero fill with the same addressing (no LDS round trip)
+        if (vox_ok) {
+#pragma unroll
+            for (int p = 0; p < (CT + 3) / 4; ++p) {
+                const int c = cfirst + 4 * p;
+                if (c < CT && cbase + c < P.C) {
+                    float *dst = dst0 + (size_t)(4 * p) * D3;
+                    if (P.vec_store) {
+                        store_f4(dst, make_float4(0.f, 0.f, 0.f, 0.f), P.store_kind);
+                    } else {
+                        for (int k = 0; k < 4; ++k)
+                            if (zq + k < D) dst[k] = 0.0f;
+                    }
+                }
+            }
+        }
+        MVX_STAMP(7)
+        return;
+    }
+    const int col = 4 * wave + lz;
+    const int rxy = lx * 4 + ly;
 #pragma unroll
     for (int rd = 0; rd < NROUND; ++rd) {
-        if (rd > 0) __syncthreads(); // previous tile fully read
+        __syncthreads(); // candidate rows (round 0) / previous tile (later rounds) fully consumed
 #pragma unroll
         for (int c = 0; c < CR; ++c) {
             const int cg = rd * CR + c;
@@ -480,17 +649,18 @@ __device__ __forceinline__ void write_out(const float2v (&acc)[(CT + 1) / 2], fl
             tile[(c * 16 + rxy) * RS + col] = v;
         }
         __syncthreads();
+        if (rd == 0) { MVX_STAMP(5) }
         if (vox_ok) {
 #pragma unroll
             for (int p = 0; p < (CR + 3) / 4; ++p) {
                 const int c = cfirst + 4 * p; // channel inside the round
-                if (c < CR && cbase + rd * CR + c < C) {
+                if (c < CR && cbase + rd * CR + c < P.C) {
                     const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 64 * p) * RS + 4 * q);
                     float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
-                    if (no_stores) {
-                        if (v.x == 123.456f) dst[0] = v.y; // timing experiment only
-                    } else if (vec_store) {
-                        store_f4(dst, v, store_kind);
+                    if (P.ablate & 4) {
+                        if (v.x == 123.456f) dst[0] = v.y; // timing experiment: no stores
+                    } else if (P.vec_store) {
+                        store_f4(dst, v, P.store_kind);
                     } else {
                         const float e4[4] = {v.x, v.y, v.z, v.w};
                         for (int k = 0; k < 4; ++k)
@@ -500,299 +670,8 @@ __device__ __forceinline__ void write_out(const float2v (&acc)[(CT + 1) / 2], fl
             }
         }
     }
-}
-
-template <int CT>
-__device__ __forceinline__ void write_zeros(bool vox_ok, int cfirst, float *dst0, size_t D3, int cbase, int C, int zq, int D,
-                                            int vec_store, int store_kind) {
-    if (!vox_ok) return;
-#pragma unroll
-    for (int p = 0; p < (CT + 3) / 4; ++p) {
-        const int c = cfirst + 4 * p;
-        if (c < CT && cbase + c < C) {
-            float *dst = dst0 + (size_t)(4 * p) * D3;
-            if (vec_store) {
-                store_f4(dst, make_float4(0.f, 0.f, 0.f, 0.f), store_kind);
-            } else {
-                for (int k = 0; k < 4; ++k)
-                    if (zq + k < D) dst[k] = 0.0f;
-            }
-        }
-    }
-}
-
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
-__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
-    voxelize_kernel(const unsigned *__restrict__ rows, const uint2 *__restrict__ xlist,
-                    const int *__restrict__ xcount, const int64_t *__restrict__ offsets,
-                    const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
-                    int *__restrict__ overflow, const VoxParams P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SW = 16 + (CT < 4 ? 4 : CT); // LDS words per candidate row (multiple of 4)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = P.NW;
-    const int nthreads = NW * 64;
-    const int D = P.D;
-
-    uint2 *xl_s = reinterpret_cast<uint2 *>(smem);
-    int *list_s = reinterpret_cast<int *>(smem + 8 * XCAP);          // [2][XCAP]
-    unsigned *zr_s = reinterpret_cast<unsigned *>(smem + 16 * XCAP); // [2][XCAP]
-    int *nl_s = reinterpret_cast<int *>(smem + 24 * XCAP);           // [2]
-    unsigned *un = reinterpret_cast<unsigned *>(smem + LDS_FIXED);
-    float *tile = reinterpret_cast<float *>(un);
-
-    // ---- block -> (molecule, channel chunk, x-slab, group of y-slabs, z chunk) ----------------------
-    const int zc = blockIdx.x;
-    const int sx = (int)((blockIdx.y * (unsigned)P.ngrp_inv) >> 24); // blockIdx.y / ngrp (exact: y < 2^16, ngrp <= 256)
-    const int sy0 = (blockIdx.y - sx * P.ngrp) * P.G;
-    const int nslab = (P.nsx - sy0) < P.G ? (P.nsx - sy0) : P.G;
-    int b = blockIdx.z, cc = 0;
-    if (P.ncc > 1) {
-        b = blockIdx.z / P.ncc;
-        cc = blockIdx.z - b * P.ncc;
-    }
-    const int cbase = cc * 32;
-    const int x0 = 4 * sx, z0 = zc * 4 * NW;
-    const int zt_lo = zc * NW, zt_hi = zt_lo + NW - 1; // sub-tile index range of the slabs along z
-    const uint2 *__restrict__ xl = xlist + ((size_t)b * P.nsx + sx) * (size_t)P.xstride;
-    // x-list -> LDS (the region has a fixed stride: these loads do not wait for the list length)
-    for (int i = tid; i < XCAP; i += nthreads) xl_s[i] = (i < P.xstride) ? xl[i] : make_uint2(0u, EMPTY_ENTRY);
-    const int nx = (P.ablate & 2) ? 0 : xcount[b * P.nsx + sx];
-    const int64_t a0 = offsets[b];
-
-    // slab id for the overflow list: ((molecule*ncc + cc) * nsx + sx) * nsx + sy) * nzc + zc
-    const int slab_base = ((blockIdx.z * P.nsx + sx) * P.nsx) * P.nzc + zc;
-    if (nx > XCAP) { // x-list does not fit: the generic kernel produces all slabs of this workgroup
-        if (tid < nslab) {
-            const int pos = atomicAdd(overflow, 1);
-            overflow[1 + pos] = slab_base + (sy0 + tid) * P.nzc;
-        }
-        return;
-    }
-
-    // ---- this lane's voxel (x and z fixed for the workgroup, y per slab) -----------------------------
-    const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
-    const int ix = x0 + lx, iz = z0 + 4 * wave + lz;
-    const double gx = (double)ix * P.res - P.half; // axis[i] = i*res - width/2, numpy/voxelizer.py:41-43
-    const double gz = (double)iz * P.res - P.half;
-    const int zt_w = zt_lo + wave; // this wave's sub-tile index along z
-    // row word this lane stages: 0-15 record, 16.. the CT channel weights of chunk cc
-    const int lane_word = lane < 16 ? lane : lane + cbase;
-    const bool stager = lane < 16 + CT;
-    const int cap = 8 * NW; // candidate rows one slab may use on this path
-
-    // write-out geometry (per thread)
-    const int RS = row_stride_floats(NW);
-    const size_t D3 = (size_t)D * D * D;
-    const int q = tid % NW;      // float4 slot inside a row
-    const int rfirst = tid / NW; // 0..63: row of this thread in pass 0; rows advance by 64 (= 4 channels) per pass
-    const int zq = z0 + 4 * q;
-    const int sxx = (rfirst >> 2) & 3, syy = rfirst & 3, cfirst = rfirst >> 4;
-    const bool xz_ok = (x0 + sxx < D) && (zq < D);
-    float *const dst_xz = out + ((size_t)b * P.C + cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D * D + zq;
-    const int col = 4 * wave + lz;
-    const int rxy = lx * 4 + ly;
-
-    // compaction of the LDS x-list against slab sy: one wave, atom order kept
-    auto scan_slab = [&](int sy, int buf) {
-        int *list = list_s + buf * XCAP;
-        unsigned *zr = zr_s + buf * XCAP;
-        int n = 0;
-        for (int i0 = 0; i0 < nx; i0 += 64) {
-            const int i = i0 + lane;
-            const uint2 en = xl_s[i < XCAP ? i : XCAP - 1];
-            const unsigned pk = (i < nx) ? en.y : EMPTY_ENTRY;
-            // packed slab ranges: y lo | y hi << 8 | z sub-tile lo << 16 | z sub-tile hi << 24
-            const bool m = ((int)(pk & 0xff) <= sy) && ((int)((pk >> 8) & 0xff) >= sy) &&
-                           ((int)((pk >> 16) & 0xff) <= zt_hi) && ((int)(pk >> 24) >= zt_lo);
-            const unsigned long long mask = __ballot(m);
-            if (m) {
-                const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                list[pos] = (int)en.x;
-                zr[pos] = pk;
-            }
-            n += __popcll(mask);
-        }
-        if (lane == 0) nl_s[buf] = n;
-    };
-
-    unsigned pre[8]; // rows of the next slab, prefetched: candidates wave + u*NW, u = 0..7
-    auto prefetch = [&](int buf) {
-        const int n = nl_s[buf];
-        const int *list = list_s + buf * XCAP;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = wave + u * NW;
-            pre[u] = 0u;
-            if (j < n && n <= cap && stager) pre[u] = rows[(size_t)(a0 + list[j]) * (size_t)P.row_words + lane_word];
-        }
-    };
-
-    __syncthreads(); // x-list in LDS
-    if (wave == 0) scan_slab(sy0, 0);
-    __syncthreads();
-    prefetch(0);
-
-    float2v acc[(CT + 1) / 2];
-    for (int si = 0; si < nslab; ++si) {
-        const int sy = sy0 + si;
-        const int iy = 4 * sy + ly;
-        const double gy = (double)iy * P.res - P.half;
-        const int buf = si & 1;
-        const int nl = nl_s[buf];
-        const bool live = nl > 0 && nl <= cap;
-#pragma unroll
-        for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
-        if (live) {
-            // A. prefetched rows -> LDS (the union region is free: the previous write-out ended with a barrier)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = wave + u * NW;
-                if (j < nl && stager) un[j * SW + lane] = pre[u];
-            }
-        }
-        // B. one wave prepares the next slab's candidate list while the others start walking
-        if (si + 1 < nslab && wave == (si + 1) % NW) scan_slab(sy + 1, buf ^ 1);
-        __syncthreads();
-        // C. walk
-        if (live && !(P.ablate & 1))
-            walk_candidates<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, un, zr_s + buf * XCAP, nl, lane, zt_w, gx, gy, gz, ix, iy,
-                                                             iz, cbase, P.C, Tc, kc);
-        __syncthreads(); // D. walk done everywhere; next slab's list published
-        // E. issue the loads of the next slab's rows; they fly during the write-out below
-        if (si + 1 < nslab) prefetch(buf ^ 1);
-        // F. write-out
-        const bool vox_ok = xz_ok && (4 * sy + syy < D);
-        float *dst0 = dst_xz + (size_t)(4 * sy + syy) * D;
-        if (nl > cap) { // too many candidates for this path: hand the slab to the generic kernel
-            if (tid == 0) {
-                const int pos = atomicAdd(overflow, 1);
-                overflow[1 + pos] = slab_base + sy * P.nzc;
-            }
-        } else if (nl == 0) {
-            write_zeros<CT>(vox_ok, cfirst, dst0, D3, cbase, P.C, zq, D, P.vec_store, P.store_kind);
-        } else {
-            write_out<CT>(acc, tile, RS, rxy, col, rfirst, q, cfirst, vox_ok, dst0, D3, cbase, P.C, zq, D, P.vec_store,
-                          P.store_kind, (P.ablate & 4) != 0);
-            __syncthreads(); // tile consumed: the union region may take the next slab's rows
-        }
-    }
-}
-
-// voxelize_generic_kernel: any x-list length, any number of candidates; nothing prefetched. A fixed grid of
-// workgroups loops over the slab ids the fast kernel put on the overflow list (usually none: immediate exit).
-// LDS map: [0, 4*XCAP) int list[] | [4*XCAP, 8*XCAP) uint32 zr[] | int nl (+pad) | union { dcap rows ; tile }
-constexpr int GEN_FIXED = 8 * XCAP + 16;
-
-int32_t generic_dcap(int32_t ct, int32_t NW) {
-    const int cr = ct < 16 ? ct : 16;
-    const size_t tile = (size_t)cr * 16 * row_stride_floats(NW) * 4;
-    int cap = (int)(tile / ((size_t)cand_stride_words(ct) * 4));
-    if (cap < 64) cap = 64;
-    if (cap > XCAP) cap = XCAP;
-    return cap;
-}
-
-size_t generic_lds_bytes(int32_t ct, int32_t NW) {
-    const int cr = ct < 16 ? ct : 16;
-    const size_t tile = (size_t)cr * 16 * row_stride_floats(NW) * 4;
-    const size_t cand = (size_t)generic_dcap(ct, NW) * cand_stride_words(ct) * 4;
-    return (size_t)GEN_FIXED + (tile > cand ? tile : cand);
-}
-
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
-__global__ void __launch_bounds__(1024)
-    voxelize_generic_kernel(const unsigned *__restrict__ rows, const uint2 *__restrict__ xlist,
-                            const int *__restrict__ xcount, const int64_t *__restrict__ offsets,
-                            const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
-                            const int *__restrict__ overflow, const VoxParams P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SW = 16 + (CT < 4 ? 4 : CT);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = P.NW;
-    const int D = P.D;
-    int *list = reinterpret_cast<int *>(smem);
-    unsigned *zr = reinterpret_cast<unsigned *>(smem + 4 * XCAP);
-    int *nl_s = reinterpret_cast<int *>(smem + 8 * XCAP);
-    unsigned *un = reinterpret_cast<unsigned *>(smem + GEN_FIXED);
-    float *tile = reinterpret_cast<float *>(un);
-    const int count = overflow[0];
-    const int RS = row_stride_floats(NW);
-    const size_t D3 = (size_t)D * D * D;
-    const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
-    const int q = tid % NW, rfirst = tid / NW;
-    const int sxx = (rfirst >> 2) & 3, syy = rfirst & 3, cfirst = rfirst >> 4;
-    const int col = 4 * wave + lz, rxy = lx * 4 + ly;
-    const bool stager = lane < 16 + CT;
-
-    for (int w = blockIdx.x; w < count; w += gridDim.x) {
-        int id = overflow[1 + w];
-        const int zc = id % P.nzc;
-        id /= P.nzc;
-        const int sy = id % P.nsx;
-        id /= P.nsx;
-        const int sx = id % P.nsx;
-        id /= P.nsx;
-        const int cc = id % P.ncc;
-        const int b = id / P.ncc;
-        const int cbase = cc * 32;
-        const int x0 = 4 * sx, y0 = 4 * sy, z0 = zc * 4 * NW;
-        const int zt_lo = zc * NW, zt_hi = zt_lo + NW - 1, zt_w = zt_lo + wave;
-        const uint2 *__restrict__ xl = xlist + ((size_t)b * P.nsx + sx) * (size_t)P.xstride;
-        const int nx = xcount[b * P.nsx + sx];
-        const int64_t a0 = offsets[b];
-        const int ix = x0 + lx, iy = y0 + ly, iz = z0 + 4 * wave + lz;
-        const double gx = (double)ix * P.res - P.half, gy = (double)iy * P.res - P.half, gz = (double)iz * P.res - P.half;
-        const int lane_word = lane < 16 ? lane : lane + cbase;
-        float2v acc[(CT + 1) / 2];
-#pragma unroll
-        for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
-
-        for (int cbeg = 0; cbeg < nx; cbeg += XCAP) {
-            const int cend = (cbeg + XCAP) < nx ? (cbeg + XCAP) : nx;
-            __syncthreads(); // previous users of list / rows are done
-            if (wave == 0) { // ordered compaction of entries [cbeg, cend)
-                int n = 0;
-                for (int i0 = cbeg; i0 < cend; i0 += 64) {
-                    const int i = i0 + lane;
-                    const uint2 en = (i < cend) ? xl[i] : make_uint2(0u, EMPTY_ENTRY);
-                    const unsigned pk = en.y;
-                    const bool m = ((int)(pk & 0xff) <= sy) && ((int)((pk >> 8) & 0xff) >= sy) &&
-                                   ((int)((pk >> 16) & 0xff) <= zt_hi) && ((int)(pk >> 24) >= zt_lo);
-                    const unsigned long long mask = __ballot(m);
-                    if (m) {
-                        const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        list[pos] = (int)en.x;
-                        zr[pos] = pk;
-                    }
-                    n += __popcll(mask);
-                }
-                if (lane == 0) nl_s[0] = n;
-            }
-            __syncthreads();
-            const int nl = nl_s[0];
-            for (int c0 = 0; c0 < nl; c0 += P.dcap) {
-                const int n = (nl - c0) < P.dcap ? (nl - c0) : P.dcap;
-                if (c0 > 0) __syncthreads();
-                for (int j = wave; j < n; j += NW)
-                    if (stager) un[j * SW + lane] = rows[(size_t)(a0 + list[c0 + j]) * (size_t)P.row_words + lane_word];
-                __syncthreads();
-                walk_candidates<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, un, zr + c0, n, lane, zt_w, gx, gy, gz, ix, iy, iz,
-                                                                 cbase, P.C, Tc, kc);
-            }
-        }
-        __syncthreads();
-        const int zq = z0 + 4 * q;
-        const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
-        float *dst0 = out + ((size_t)b * P.C + cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D * D + (size_t)(y0 + syy) * D + zq;
-        write_out<CT>(acc, tile, RS, rxy, col, rfirst, q, cfirst, vox_ok, dst0, D3, cbase, P.C, zq, D, P.vec_store,
-                      P.store_kind, false);
-    }
+    MVX_STAMP(7)
+#undef MVX_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -831,17 +710,6 @@ static hipError_t for_kernel(const KernelKey &k, Fn &&fn) {
     return hipErrorInvalidValue;
 }
 
-template <typename K>
-static hipError_t raise_lds_limit(K kernel, size_t lds, size_t &raised) {
-    if (lds > 64 * 1024 && lds > raised) { // above the default dynamic-LDS limit: raise it once per instantiation
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        raised = lds;
-    }
-    return hipSuccess;
-}
-
 struct LaunchFn {
     const VoxArgs &a;
     hipStream_t s;
@@ -849,39 +717,21 @@ struct LaunchFn {
     hipError_t operator()() const {
         const VoxParams &p = a.p;
         if (p.B <= 0) return hipSuccess;
-        if ((long long)p.nsx * p.ngrp > 65535 || (long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
-        hipError_t e;
-        {
+        if ((long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
+        const size_t lds = voxelize_lds_bytes(CT, p.NW);
+        if (lds > 64 * 1024) { // above the default dynamic-LDS limit: raise it once per instantiation
             static size_t raised = 0;
-            const size_t lds = voxelize_lds_bytes(CT, p.NW);
-            auto kern = &voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>;
-            if ((e = raise_lds_limit(kern, lds, raised)) != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3((unsigned)p.nzc, (unsigned)(p.nsx * p.ngrp), (unsigned)(p.B * p.ncc)),
-                               dim3(p.NW * 64), lds, s, a.rows, a.xlist, a.xcount, a.offsets, a.Tc, a.kc, a.out, a.overflow,
-                               a.p);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (lds > raised) {
+                hipError_t e = hipFuncSetAttribute(
+                    reinterpret_cast<const void *>(&voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                raised = lds;
+            }
         }
-        if (MAXT == 512) { // one generic instantiation per (CT, GAUSS, CHANWISE, LANE_RANGE)
-            static size_t raised = 0;
-            const size_t lds = generic_lds_bytes(CT, p.NW);
-            auto kern = &voxelize_generic_kernel<CT, GAUSS, CHANWISE, LANE_RANGE>;
-            if ((e = raise_lds_limit(kern, lds, raised)) != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(512), dim3(p.NW * 64), lds, s, a.rows, a.xlist, a.xcount, a.offsets, a.Tc, a.kc,
-                               a.out, a.overflow, a.p);
-            return hipGetLastError();
-        }
-        return LaunchGeneric<CT, GAUSS, CHANWISE, LANE_RANGE>();
-    }
-    template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
-    hipError_t LaunchGeneric() const {
-        static size_t raised = 0;
-        const VoxParams &p = a.p;
-        const size_t lds = generic_lds_bytes(CT, p.NW);
-        auto kern = &voxelize_generic_kernel<CT, GAUSS, CHANWISE, LANE_RANGE>;
-        hipError_t e;
-        if ((e = raise_lds_limit(kern, lds, raised)) != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(512), dim3(p.NW * 64), lds, s, a.rows, a.xlist, a.xcount, a.offsets, a.Tc, a.kc, a.out,
-                           a.overflow, a.p);
+        hipLaunchKernelGGL((voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>),
+                           dim3((unsigned)(p.nzc * p.nsx * p.nsx), (unsigned)(p.B * p.ncc)), dim3(p.NW * 64), lds, s, a.rows,
+                           a.xlist, a.Tc, a.kc, a.out, a.p);
         return hipGetLastError();
     }
 };
