@@ -69,6 +69,7 @@ struct mvx_handle {
     size_t stamp_blocks = 0;
     DevBuf stamps;
     int row_bytes = 64;
+    int max_ct = 32;
     int xcd_swap = 0; // measured slower on cfg-2 (0.61 vs 0.56 ms): kept as an experiment knob (MVX_XCD_SWAP=1)
     int store_kind = 1; // nt: measured 0.69 -> 0.54 ms on cfg-2 (output lines do not displace the re-read inputs in L2)
 };
@@ -251,9 +252,10 @@ int run(mvx_handle *h, const RunArgs &r) {
 
     // ---- workspace --------------------------------------------------------------------------------
     const size_t n_alloc = (size_t)std::max<int64_t>(total, 1);
-    const int ct = pick_ct(std::min(r.C, 32));
-    const int ncc = (r.C + 31) / 32;
-    const int Cpad = (ncc > 1) ? ncc * 32 : (ct < 4 ? 4 : ct); // channel weights per row, zero padded
+    // channels per workgroup (register accumulators per lane); more channels -> several channel chunks
+    const int ct = pick_ct(std::min(r.C, h->max_ct));
+    const int ncc = (r.C + ct - 1) / ct;
+    const int Cpad = (ncc > 1) ? ncc * ct : (ct < 4 ? 4 : ct); // channel weights per row, zero padded
     const int row_words = 16 + Cpad;
     if ((rc = ensure(h->rec, n_alloc * (size_t)row_words * 4))) return rc;
     h->row_bytes = row_words * 4;
@@ -421,6 +423,7 @@ int mvx_create(const mvx_config *cfg, mvx_handle **out) {
     if (const char *env = std::getenv("MVX_ABLATE")) h->ablate = std::atoi(env);
     if (const char *env = std::getenv("MVX_STAMPS")) h->want_stamps = std::atoi(env);
     if (const char *env = std::getenv("MVX_STORE")) h->store_kind = std::atoi(env);
+    if (const char *env = std::getenv("MVX_CT")) h->max_ct = std::max(1, std::min(32, std::atoi(env)));
     if (const char *env = std::getenv("MVX_XCD_SWAP")) h->xcd_swap = std::atoi(env);
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) {

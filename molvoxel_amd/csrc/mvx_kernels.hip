@@ -421,9 +421,17 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // diagnostic builds only (MVX_STAMPS): phase time stamps of thread 0 into a buffer nothing else reads
+#ifdef MVX_DIAG
     const size_t blk = blockIdx.x + (size_t)gridDim.x * blockIdx.y;
+#endif
+#ifdef MVX_DIAG
 #define MVX_STAMP(k) \
     if (P.stamps && tid == 0) P.stamps[blk * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#define MVX_ABLATE(bit) (P.ablate & (bit))
+#else
+#define MVX_STAMP(k)
+#define MVX_ABLATE(bit) 0
+#endif
     MVX_STAMP(0)
     const int NW = P.NW;
     const int SB = NW < 8 ? NW : 8; // x-list entries per lane and scan round
@@ -471,7 +479,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
             e[u] = (u < SB && i < P.xstride) ? xl[i] : kEmpty;
         }
         // header -> LDS for the other waves (they read it after the first barrier)
-        if (lane == 0) nlist_s[1] = (P.ablate & 2) ? XL_HEADER : (int)e[0].x + XL_HEADER;
+        if (lane == 0) nlist_s[1] = MVX_ABLATE(2) ? XL_HEADER : (int)e[0].x + XL_HEADER;
         if (lane == 1) nlist_s[2] = (int)e[0].x;
     }
     MVX_STAMP(1)
@@ -484,7 +492,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
     const double gz = (double)iz * P.res - P.half;
     const int zt_w = zt_lo + wave; // this wave's sub-tile index along z
     // row word this lane stages: 0-15 record, 16.. the CT channel weights of chunk cc
-    const int lane_word = lane < 16 ? lane : lane + cc * 32;
+    const int lane_word = lane < 16 ? lane : lane + cc * CT;
     const bool stager = lane < 16 + CT;
 
     float2v acc[(CT + 1) / 2];
@@ -498,7 +506,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
         // ---- 1. wave 0: ordered compaction of LCAP x-list entries against the slab's y/z box ---------
         if (wave == 0) {
             const int nxw = (base == 0) ? __builtin_amdgcn_readlane((int)e[0].x, 0) + XL_HEADER : nx;
-            const int nxe = (P.ablate & 2) ? XL_HEADER : nxw;
+            const int nxe = MVX_ABLATE(2) ? XL_HEADER : nxw;
             int n = 0;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -550,7 +558,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
             MVX_STAMP(3)
 
             // ---- 3. walk the candidates that touch this wave's sub-tile ------------------------------
-            for (int jb = 0; jb < ((P.ablate & 1) ? 0 : n); jb += 64) {
+            for (int jb = 0; jb < (MVX_ABLATE(1) ? 0 : n); jb += 64) {
                 const int j = jb + lane;
                 bool ok = false;
                 if (j < n) {
@@ -584,7 +592,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
                     if constexpr (CHANWISE) {
 #pragma unroll
                         for (int c = 0; c < CT; ++c) {
-                            const int ch = (cc * 32 + c < P.C) ? cc * 32 + c : P.C - 1;
+                            const int ch = (cc * CT + c < P.C) ? cc * CT + c : P.C - 1;
                             const float ev = GAUSS ? __builtin_amdgcn_exp2f(kc[ch] * d2f) : 1.0f;
                             const float vc = (hit && d2 <= Tc[ch]) ? ev : 0.0f;
                             if (c & 1) acc[c / 2].y = fmaf(vc, f[c], acc[c / 2].y);
@@ -615,7 +623,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
     const int zq = z0 + 4 * q;
     const int sxx = (rfirst >> 2) & 3, syy = rfirst & 3, cfirst = rfirst >> 4;
     const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
-    const int cbase = cc * 32;
+    const int cbase = cc * CT;
     float *dst0 = out + ((size_t)b * P.C + cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
     if (!any_candidate) {
         // empty slab: pure zero fill with the same addressing (no LDS round trip)
@@ -657,7 +665,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
                 if (c < CR && cbase + rd * CR + c < P.C) {
                     const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 64 * p) * RS + 4 * q);
                     float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
-                    if (P.ablate & 4) {
+                    if (MVX_ABLATE(4)) {
                         if (v.x == 123.456f) dst[0] = v.y; // timing experiment: no stores
                     } else if (P.vec_store) {
                         store_f4(dst, v, P.store_kind);
@@ -672,6 +680,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
     }
     MVX_STAMP(7)
 #undef MVX_STAMP
+#undef MVX_ABLATE
 }
 
 // ------------------------------------------------------------------------------------------------
