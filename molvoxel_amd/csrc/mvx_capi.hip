@@ -313,33 +313,34 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.D = D;
     va.p.C = r.C;
     va.p.B = r.B;
-    // slab = 4 x 4 x (4*NW) voxels, NW waves. Keep z-runs whole 128-B lines: 8 sub-tiles (32 floats) per
-    // workgroup when the row length allows it, otherwise one workgroup per full row (<= 16 sub-tiles).
-    const int nz4 = (D + 3) / 4;
+    // slab = SUBX x SUBY x (SUBZ*NW) voxels, NW waves side by side along z. Prefer whole rows (NW = row length in
+    // sub-tiles) up to 8 waves; longer rows are cut into chunks of 8 sub-tiles (256-B runs).
+    const int nsx = (D + SUBX - 1) / SUBX, nsy = (D + SUBY - 1) / SUBY, nsz = (D + SUBZ - 1) / SUBZ;
     int NW, nzc;
-    if (nz4 <= 8 || (nz4 <= 16 && nz4 % 8 != 0)) {
-        NW = nz4;
+    if (nsz <= 8) {
+        NW = nsz;
         nzc = 1;
     } else {
         NW = 8;
-        nzc = (nz4 + 7) / 8;
+        nzc = (nsz + 7) / 8;
     }
     if (h->force_nw > 0 && h->force_nw <= 16) {
-        NW = std::min(h->force_nw, nz4);
-        nzc = (nz4 + NW - 1) / NW;
+        NW = std::min(h->force_nw, nsz);
+        nzc = (nsz + NW - 1) / NW;
     }
-    va.p.nsx = nz4;
-    va.p.nsx_inv = (uint32_t)((0x100000000ull + (uint64_t)nz4 - 1) / (uint64_t)nz4);
+    va.p.nsx = nsx;
+    va.p.nsy = nsy;
+    va.p.nsy_inv = (uint32_t)((0x100000000ull + (uint64_t)nsy - 1) / (uint64_t)nsy);
     va.p.nzc = nzc;
     va.p.nzc_inv = (nzc == 1) ? 0xffffffffu : (uint32_t)((0x100000000ull + (uint64_t)nzc - 1) / (uint64_t)nzc);
-    va.p.xcd_swap = (h->xcd_swap && ((long long)nzc * nz4 * nz4) % 8 == 0) ? 1 : 0;
+    va.p.xcd_swap = (h->xcd_swap && ((long long)nzc * nsy * nsx) % 8 == 0) ? 1 : 0;
     va.p.NW = NW;
     // x-slab binning (ordered lists per (molecule, x-slab), fixed-stride regions)
     int64_t nmax = 1;
     for (int b = 0; b < r.B; ++b) nmax = std::max<int64_t>(nmax, r.offsets[b + 1] - r.offsets[b]);
     const int64_t xstride = nmax + 2; // two header entries per list
-    if ((rc = ensure(h->xlist, (size_t)r.B * nz4 * (size_t)xstride * sizeof(uint2)))) return rc;
-    HIP_TRY(launch_xbin(pa.bbox, d_off, r.B, nz4, (int32_t)xstride, reinterpret_cast<uint2 *>(h->xlist.p), s));
+    if ((rc = ensure(h->xlist, (size_t)r.B * nsx * (size_t)xstride * sizeof(uint2)))) return rc;
+    HIP_TRY(launch_xbin(pa.bbox, d_off, r.B, nsx, (int32_t)xstride, reinterpret_cast<uint2 *>(h->xlist.p), s));
     va.p.xstride = (int32_t)xstride;
     va.xlist = reinterpret_cast<const uint2 *>(h->xlist.p);
     va.p.ncc = ncc;
@@ -348,16 +349,16 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.ablate = h->ablate;
     va.p.stamps = nullptr;
     if (h->want_stamps) {
-        const size_t nblk = (size_t)r.B * ncc * nz4 * nz4 * nzc;
+        const size_t nblk = (size_t)r.B * ncc * nsx * nsy * nzc;
         if ((rc = ensure(h->stamps, nblk * 8 * sizeof(unsigned long long)))) return rc;
         HIP_TRY(hipMemsetAsync(h->stamps.p, 0, nblk * 8 * sizeof(unsigned long long), s));
         va.p.stamps = reinterpret_cast<unsigned long long *>(h->stamps.p);
         h->stamp_blocks = nblk;
     }
     va.p.store_kind = h->store_kind;
-    // a 4^3 sub-tile lies inside one reference block when 4 | blockdim (or there is a single block):
+    // a sub-tile lies inside one reference block when its edges divide blockdim (or there is a single block):
     // the block cull is then wave-uniform and already folded into the candidate ranges.
-    const bool lane_range = !(g.nb == 1 || g.bd % 4 == 0);
+    const bool lane_range = !(g.nb == 1 || (g.bd % SUBX == 0 && g.bd % SUBY == 0 && g.bd % SUBZ == 0));
     const bool timed = h->profiling && h->ev_count < MVX_PROFILE_RING;
     if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count], s));
     HIP_TRY(launch_voxelize(va, ct, gauss, chanwise, lane_range, s));

@@ -7,6 +7,14 @@
 
 namespace mvx {
 
+// Sub-tile owned by one wave (one voxel per lane): SUBX x SUBY x SUBZ = 64 voxels. 2 x 4 x 8 keeps the footprint
+// compact (Minkowski volume with a radius-2-voxel ball: 497 voxels vs 440 for 4^3, 1442 for 1 x 1 x 64) while eight
+// waves side by side along z cover whole 256-B rows (4 y-rows of one (channel, x) plane = 1 KiB contiguous).
+constexpr int SUBX_SH = 1, SUBY_SH = 2, SUBZ_SH = 3;
+constexpr int SUBX = 1 << SUBX_SH, SUBY = 1 << SUBY_SH, SUBZ = 1 << SUBZ_SH;
+static_assert(SUBX * SUBY * SUBZ == 64, "one voxel per lane");
+constexpr int RPC = SUBX * SUBY; // tile rows per channel
+
 // Per-atom record written by the prep kernel and consumed by the voxelize kernel (64 B, AoS so
 // that one 16-lane dword load moves a whole record into LDS).
 struct __attribute__((aligned(16))) AtomRec {
@@ -55,8 +63,8 @@ struct PrepArgs {
 struct VoxParams { // by-value kernel parameters (scalars only: pointers are separate __restrict__ arguments)
     double res, half;
     int32_t D, C, B;
-    int32_t nsx, nzc, ncc; // slabs per x/y axis, z chunks, channel chunks
-    uint32_t nsx_inv, nzc_inv; // ceil(2^32 / d): n / d == __umulhi(n, inv) for the slab ids used here (n * d < 2^32)
+    int32_t nsx, nsy, nzc, ncc; // slabs along x, along y, z chunks, channel chunks
+    uint32_t nsy_inv, nzc_inv; // ceil(2^32 / d): n / d == __umulhi(n, inv) for the slab ids used here (n * d < 2^32)
     int32_t xcd_swap;      // 1: swap the low 3 bits of slab id and molecule id (XCD-affine molecules; experiment knob MVX_XCD_SWAP=1, default off)
     int32_t NW;            // waves per workgroup = 4^3 sub-tiles per slab
     int32_t row_words;     // words per atom row (16 + Cpad)

@@ -31,6 +31,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <cstdlib>
 
 // cdist-order arithmetic must not be fused, whatever flags the TU is built with.
 #pragma clang fp contract(off)
@@ -304,11 +305,11 @@ hipError_t launch_pack_channels(float *rows, int32_t row_words, int32_t Cpad, in
 }
 
 // ------------------------------------------------------------------------------------------------
-// x-slab binning: ordered list of the atoms whose admitted x-range touches each 4-voxel x-slab
+// x-slab binning: ordered list of the atoms whose admitted x-range touches each SUBX-voxel x-slab
 // ------------------------------------------------------------------------------------------------
 // One wave per (molecule, x-slab). Entries keep atom order (ballot + prefix compaction, no atomics,
 // so downstream float sums are reproducible). Entry = {atom index in molecule, packed slab ranges}: the
-// admitted y range in 4-voxel slabs (lo | hi << 8) and the admitted z range in 4-voxel sub-tiles
+// admitted y range in SUBY-voxel slabs (lo | hi << 8) and the admitted z range in SUBZ-voxel sub-tiles
 // (lo << 16 | hi << 24); that is all the voxelize kernel's slab / sub-tile filters need (D <= 1024). List
 // (b, sx) lives at xlist[(b*nsx + sx) * xstride] (xstride = largest molecule of the batch), its length in
 // xcount[b*nsx+sx].
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(64) xbin_kernel(const uint4 *bbox, const int64
     const int b = blockIdx.x / nsx, sx = blockIdx.x % nsx;
     const int lane = threadIdx.x;
     const int64_t a0 = offsets[b], a1 = offsets[b + 1];
-    const int x0 = 4 * sx;
+    const int x0 = SUBX * sx;
     uint2 *dst = xlist + (size_t)blockIdx.x * (size_t)xstride; // fixed stride: addressable from blockIdx alone
     int count = 0;
     for (int64_t base = a0; base < a1; base += 64) {
@@ -329,13 +330,13 @@ __global__ void __launch_bounds__(64) xbin_kernel(const uint4 *bbox, const int64
         uint4 bb = make_uint4(0, 0, 0, 0);
         if (a < a1) {
             bb = bbox[a];
-            m = ((int)(bb.x & 0xffff) <= x0 + 3) && ((int)(bb.x >> 16) >= x0);
+            m = ((int)(bb.x & 0xffff) <= x0 + SUBX - 1) && ((int)(bb.x >> 16) >= x0);
         }
         const unsigned long long mask = __ballot(m);
         if (m) {
             const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-            const unsigned packed = ((bb.y & 0xffff) >> 2) | (((bb.y >> 16) >> 2) << 8) | (((bb.z & 0xffff) >> 2) << 16) |
-                                    (((bb.z >> 16) >> 2) << 24);
+            const unsigned packed = ((bb.y & 0xffff) >> SUBY_SH) | (((bb.y >> 16) >> SUBY_SH) << 8) |
+                                    (((bb.z & 0xffff) >> SUBZ_SH) << 16) | (((bb.z >> 16) >> SUBZ_SH) << 24);
             dst[XL_HEADER + count + below] = make_uint2((unsigned)(a - a0), packed);
         }
         count += __popcll(mask);
@@ -385,14 +386,15 @@ __device__ __forceinline__ void store_f4(float *dst, const float4 v, int kind) {
     }
 }
 
-__host__ __device__ __forceinline__ int row_stride_floats(int NW) { return 4 * NW + ((NW & 1) ? 8 : 4); }
+// floats per tile row: SUBZ*NW plus a pad that keeps ds_write_b32 conflict-free for the lane -> (row, column) map
+__host__ __device__ __forceinline__ int row_stride_floats(int NW) { return SUBZ * NW + 8; }
 __host__ __device__ __forceinline__ int cand_stride_words(int ct) { return 16 + (ct < 4 ? 4 : ct); }
 
 // candidate rows staged per round: what fits in the out tile's bytes, at least 64, at most the list capacity
 int32_t voxelize_dcap(int32_t ct, int32_t NW) {
     const int cr = ct < 16 ? ct : 16;
     const int lcap = 64 * (NW < 8 ? NW : 8);
-    const size_t tile = (size_t)cr * 16 * row_stride_floats(NW) * 4;
+    const size_t tile = (size_t)cr * RPC * row_stride_floats(NW) * 4;
     int cap = (int)(tile / ((size_t)cand_stride_words(ct) * 4));
     if (cap < 64) cap = 64;
     if (cap > lcap) cap = lcap;
@@ -402,7 +404,7 @@ int32_t voxelize_dcap(int32_t ct, int32_t NW) {
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW) {
     const int cr = ct < 16 ? ct : 16;
     const int lcap = 64 * (NW < 8 ? NW : 8);
-    const size_t tile = (size_t)cr * 16 * row_stride_floats(NW) * 4;
+    const size_t tile = (size_t)cr * RPC * row_stride_floats(NW) * 4;
     const size_t cand = (size_t)voxelize_dcap(ct, NW) * cand_stride_words(ct) * 4;
     return (size_t)8 * lcap + 16 + (tile > cand ? tile : cand);
 }
@@ -445,7 +447,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
     float *tile = reinterpret_cast<float *>(un);
 
     // ---- block -> (molecule * ncc + channel chunk, slab) -------------------------------------------
-    // grid = (T, Z): t = zc + nzc * (sy + nsx * sx) slab id, z = molecule * ncc + chunk. Workgroups are dealt
+    // grid = (T, Z): t = zc + nzc * (sy + nsy * sx) slab id, z = molecule * ncc + chunk. Workgroups are dealt
     // round-robin over the 8 XCDs in linear order (block L -> XCD L % 8; observed, used for speed only: any
     // placement gives the same result). With T % 8 == 0 the XCD is t % 8, so swapping the low three bits of t
     // and z makes XCD k work through all slabs of molecule (z & ~7) + k: its rows and x-lists are then pulled
@@ -458,14 +460,14 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
     }
     const unsigned ty = (P.nzc == 1) ? t : __umulhi(t, P.nzc_inv); // t / nzc
     const int zc = (int)(t - ty * P.nzc);
-    const int sx = (P.nsx == 1) ? (int)ty : (int)__umulhi(ty, P.nsx_inv); // ty / nsx
-    const int sy = (int)ty - sx * P.nsx;
+    const int sx = (P.nsy == 1) ? (int)ty : (int)__umulhi(ty, P.nsy_inv); // ty / nsy
+    const int sy = (int)ty - sx * P.nsy;
     int b = (int)z, cc = 0;
     if (P.ncc > 1) {
         b = (int)z / P.ncc;
         cc = (int)z - b * P.ncc;
     }
-    const int x0 = 4 * sx, y0 = 4 * sy, z0 = zc * 4 * NW;
+    const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
     const int zt_lo = zc * NW, zt_hi = zt_lo + NW - 1; // sub-tile index range of the slab along z
     // x-list of (b, sx): fixed-stride region whose first two entries carry the list length and the molecule's
     // first atom, so nothing here waits for a dependent scalar load
@@ -485,8 +487,8 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
     MVX_STAMP(1)
 
     // ---- this lane's voxel ---------------------------------------------------------------------
-    const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
-    const int ix = x0 + lx, iy = y0 + ly, iz = z0 + 4 * wave + lz;
+    const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1), lx = lane >> (SUBZ_SH + SUBY_SH);
+    const int ix = x0 + lx, iy = y0 + ly, iz = z0 + SUBZ * wave + lz;
     const double gx = (double)ix * P.res - P.half; // axis[i] = i*res - width/2, numpy/voxelizer.py:41-43
     const double gy = (double)iy * P.res - P.half;
     const double gz = (double)iz * P.res - P.half;
@@ -495,51 +497,45 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
     const int lane_word = lane < 16 ? lane : lane + cc * CT;
     const bool stager = lane < 16 + CT;
 
-    float2v acc[(CT + 1) / 2];
-#pragma unroll
-    for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
-
     bool any_candidate = false;
-    int nx = LCAP; // entries incl. header; the real value is published with the first round's list
+    int nx = 0; // entries incl. header, published with the first round's list
     int64_t a0 = 0;
-    for (int base = 0; base < nx; base += LCAP) {
-        // ---- 1. wave 0: ordered compaction of LCAP x-list entries against the slab's y/z box ---------
-        if (wave == 0) {
-            const int nxw = (base == 0) ? __builtin_amdgcn_readlane((int)e[0].x, 0) + XL_HEADER : nx;
-            const int nxe = MVX_ABLATE(2) ? XL_HEADER : nxw;
-            int n = 0;
+    float2v acc[(CT + 1) / 2];
+
+    // ---- 1. wave 0: ordered compaction of up to LCAP x-list entries [base, ...) against the slab's y/z box.
+    // Round 0 consumes the entries already sitting in registers; the accumulators are not live yet, which keeps
+    // the prefetched entries out of scratch.
+    auto scan_round = [&](int base, int nxe, bool from_regs) {
+        int n = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (u < SB) {
-                    const int i = base + u * 64 + lane;
-                    uint2 en = e[u];
-                    if (base > 0) en = (i < nxe) ? xl[i] : kEmpty;
-                    // packed slab ranges: y lo | y hi << 8 | z sub-tile lo << 16 | z sub-tile hi << 24
-                    // (the two header entries carry EMPTY_ENTRY and never match)
-                    const bool m = (i < nxe) && ((int)(en.y & 0xff) <= sy) && ((int)((en.y >> 8) & 0xff) >= sy) &&
-                                   ((int)((en.y >> 16) & 0xff) <= zt_hi) && ((int)(en.y >> 24) >= zt_lo);
-                    const unsigned long long mask = __ballot(m);
-                    if (m) {
-                        const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        list[pos] = (int)en.x;
-                        zr_l[pos] = en.y;
-                    }
-                    n += __popcll(mask);
+        for (int u = 0; u < 8; ++u) {
+            if (u < SB) {
+                const int i = base + u * 64 + lane;
+                uint2 en = e[u];
+                if (!from_regs) en = (i < nxe) ? xl[i] : kEmpty;
+                // packed slab ranges: y lo | y hi << 8 | z sub-tile lo << 16 | z sub-tile hi << 24
+                // (the two header entries carry EMPTY_ENTRY and never match)
+                const bool m = (i < nxe) && ((int)(en.y & 0xff) <= sy) && ((int)((en.y >> 8) & 0xff) >= sy) &&
+                               ((int)((en.y >> 16) & 0xff) <= zt_hi) && ((int)(en.y >> 24) >= zt_lo);
+                const unsigned long long mask = __ballot(m);
+                if (m) {
+                    const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    list[pos] = (int)en.x;
+                    zr_l[pos] = en.y;
                 }
+                n += __popcll(mask);
             }
-            if (lane == 0) nlist_s[0] = n;
         }
-        __syncthreads(); // list complete
-        const int nl = nlist_s[0];
-        nx = nlist_s[1];
-        a0 = (int64_t)(unsigned)nlist_s[2];
-        MVX_STAMP(2)
+        if (lane == 0) nlist_s[0] = n;
+    };
+
+    // ---- 2./3. stage the listed rows in rounds of dcap and walk them ------------------------------------
+    auto process_list = [&](int nl) {
         for (int c0 = 0; c0 < nl; c0 += P.dcap) {
             const int n = (nl - c0) < P.dcap ? (nl - c0) : P.dcap; // rows staged this round
             if (c0 > 0) __syncthreads(); // previous round's rows consumed
             any_candidate = true;
-            // ---- 2. stage rows: lanes 0-15 the 64-B record, lanes 16..16+CT-1 the channel weights -------
+            // stage rows: lanes 0-15 the 64-B record, lanes 16..16+CT-1 the channel weights
             for (int j0 = wave; j0 < n; j0 += 8 * NW) {
                 unsigned v[8];
 #pragma unroll
@@ -557,7 +553,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
             __syncthreads();
             MVX_STAMP(3)
 
-            // ---- 3. walk the candidates that touch this wave's sub-tile ------------------------------
+            // walk the candidates that touch this wave's sub-tile
             for (int jb = 0; jb < (MVX_ABLATE(1) ? 0 : n); jb += 64) {
                 const int j = jb + lane;
                 bool ok = false;
@@ -612,16 +608,36 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
             }
             MVX_STAMP(4)
         }
-        if (base + LCAP < nx) __syncthreads(); // another round will overwrite the list / candidate rows
+    };
+
+    // round 0: entries prefetched in registers
+    if (wave == 0) {
+        const int nxw = __builtin_amdgcn_readlane((int)e[0].x, 0) + XL_HEADER;
+        scan_round(0, MVX_ABLATE(2) ? XL_HEADER : nxw, true);
+    }
+    __syncthreads(); // list complete
+    nx = nlist_s[1];
+    a0 = (int64_t)(unsigned)nlist_s[2];
+    MVX_STAMP(2)
+#pragma unroll
+    for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
+    process_list(nlist_s[0]);
+    // further rounds (x-lists longer than LCAP entries: dense x-slabs), nothing prefetched
+    for (int base = LCAP; base < nx; base += LCAP) {
+        __syncthreads(); // list / candidate rows of the previous round consumed
+        if (wave == 0) scan_round(base, nx, false);
+        __syncthreads();
+        process_list(nlist_s[0]);
     }
 
     // ---- 4. write-out ----------------------------------------------------------------------------
     const int RS = row_stride_floats(NW);
     const size_t D2 = (size_t)D * D, D3 = D2 * D;
-    const int q = tid % NW;      // float4 slot inside a row
-    const int rfirst = tid / NW; // 0..63: row of this thread in pass 0; rows advance by 64 (= 4 channels) per pass
+    const int F4 = (SUBZ / 4) * NW; // float4 slots per row
+    const int q = tid % F4;         // float4 slot inside a row
+    const int rfirst = tid / F4;    // row of this thread in pass 0; rows advance by 4 channels (4*RPC rows) per pass
     const int zq = z0 + 4 * q;
-    const int sxx = (rfirst >> 2) & 3, syy = rfirst & 3, cfirst = rfirst >> 4;
+    const int sxx = (rfirst >> SUBY_SH) & (SUBX - 1), syy = rfirst & (SUBY - 1), cfirst = rfirst / RPC;
     const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
     const int cbase = cc * CT;
     float *dst0 = out + ((size_t)b * P.C + cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
@@ -645,8 +661,8 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
         MVX_STAMP(7)
         return;
     }
-    const int col = 4 * wave + lz;
-    const int rxy = lx * 4 + ly;
+    const int col = SUBZ * wave + lz;
+    const int rxy = lx * SUBY + ly;
 #pragma unroll
     for (int rd = 0; rd < NROUND; ++rd) {
         __syncthreads(); // candidate rows (round 0) / previous tile (later rounds) fully consumed
@@ -654,7 +670,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
         for (int c = 0; c < CR; ++c) {
             const int cg = rd * CR + c;
             const float v = (cg & 1) ? acc[cg / 2].y : acc[cg / 2].x;
-            tile[(c * 16 + rxy) * RS + col] = v;
+            tile[(c * RPC + rxy) * RS + col] = v;
         }
         __syncthreads();
         if (rd == 0) { MVX_STAMP(5) }
@@ -663,7 +679,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
             for (int p = 0; p < (CR + 3) / 4; ++p) {
                 const int c = cfirst + 4 * p; // channel inside the round
                 if (c < CR && cbase + rd * CR + c < P.C) {
-                    const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 64 * p) * RS + 4 * q);
+                    const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 4 * RPC * p) * RS + 4 * q);
                     float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
                     if (MVX_ABLATE(4)) {
                         if (v.x == 123.456f) dst[0] = v.y; // timing experiment: no stores
@@ -727,7 +743,8 @@ struct LaunchFn {
         const VoxParams &p = a.p;
         if (p.B <= 0) return hipSuccess;
         if ((long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
-        const size_t lds = voxelize_lds_bytes(CT, p.NW);
+        static const size_t lds_pad = std::getenv("MVX_LDS_PAD") ? (size_t)std::atoi(std::getenv("MVX_LDS_PAD")) : 0; // experiments
+        const size_t lds = voxelize_lds_bytes(CT, p.NW) + lds_pad;
         if (lds > 64 * 1024) { // above the default dynamic-LDS limit: raise it once per instantiation
             static size_t raised = 0;
             if (lds > raised) {
@@ -739,7 +756,7 @@ struct LaunchFn {
             }
         }
         hipLaunchKernelGGL((voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>),
-                           dim3((unsigned)(p.nzc * p.nsx * p.nsx), (unsigned)(p.B * p.ncc)), dim3(p.NW * 64), lds, s, a.rows,
+                           dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(p.B * p.ncc)), dim3(p.NW * 64), lds, s, a.rows,
                            a.xlist, a.Tc, a.kc, a.out, a.p);
         return hipGetLastError();
     }
