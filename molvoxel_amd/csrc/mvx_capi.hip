@@ -340,7 +340,10 @@ int run(mvx_handle *h, const RunArgs &r) {
     for (int b = 0; b < r.B; ++b) nmax = std::max<int64_t>(nmax, r.offsets[b + 1] - r.offsets[b]);
     const int64_t xstride = nmax + 2; // two header entries per list
     if ((rc = ensure(h->xlist, (size_t)r.B * nsx * (size_t)xstride * sizeof(uint2)))) return rc;
-    HIP_TRY(launch_xbin(pa.bbox, d_off, r.B, nsx, (int32_t)xstride, reinterpret_cast<uint2 *>(h->xlist.p), s));
+    if ((rc = ensure(h->xcount, (size_t)r.B * nsx * nsy * nzc * 64 * sizeof(uint2)))) return rc; // slab lines
+    HIP_TRY(launch_xbin(pa.bbox, d_off, r.B, nsx, nsy, nzc, NW, (int32_t)xstride, reinterpret_cast<uint2 *>(h->xlist.p),
+                        reinterpret_cast<uint2 *>(h->xcount.p), s));
+    va.slist = reinterpret_cast<const uint2 *>(h->xcount.p);
     va.p.xstride = (int32_t)xstride;
     va.xlist = reinterpret_cast<const uint2 *>(h->xlist.p);
     va.p.ncc = ncc;

@@ -79,6 +79,7 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
 struct VoxArgs {
     const unsigned *rows;  // per-atom rows (record + channel weights)
     const uint2 *xlist;    // x-slab lists (xbin_kernel)
+    const uint2 *slist;    // per-slab candidate lines (xbin_kernel), 64 entries each
     const double *Tc;      // channel-wise features: per-channel d2 thresholds
     const float *kc;       //                        per-channel gaussian coefficients
     float *out;            // (B, C, D, D, D)
@@ -89,8 +90,8 @@ struct VoxArgs {
 hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax,
                            double *Tc, float *kc, hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
-hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, int32_t xstride, uint2 *xlist,
-                       hipStream_t s);
+hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
+                       int32_t xstride, uint2 *xlist, uint2 *slist, hipStream_t s);
 hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf_dev, double *out, hipStream_t s);
 // ct: channels per thread (1, 4, 8, 16, 32); lane_range: per-lane index-range check needed
 hipError_t launch_voxelize(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);

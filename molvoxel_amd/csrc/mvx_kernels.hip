@@ -305,72 +305,127 @@ hipError_t launch_pack_channels(float *rows, int32_t row_words, int32_t Cpad, in
 }
 
 // ------------------------------------------------------------------------------------------------
-// x-slab binning: ordered list of the atoms whose admitted x-range touches each SUBX-voxel x-slab
+// binning: ordered x-slab lists and per-slab candidate lists
 // ------------------------------------------------------------------------------------------------
-// One wave per (molecule, x-slab). Entries keep atom order (ballot + prefix compaction, no atomics,
-// so downstream float sums are reproducible). Entry = {atom index in molecule, packed slab ranges}: the
-// admitted y range in SUBY-voxel slabs (lo | hi << 8) and the admitted z range in SUBZ-voxel sub-tiles
-// (lo << 16 | hi << 24); that is all the voxelize kernel's slab / sub-tile filters need (D <= 1024). List
-// (b, sx) lives at xlist[(b*nsx + sx) * xstride] (xstride = largest molecule of the batch), its length in
-// xcount[b*nsx+sx].
+// One 256-thread block per (molecule, SUBX-voxel x-slab).
+//  A. x-list: the atoms whose admitted x range touches the slab, in atom order (ballot + prefix compaction,
+//     no atomics, so downstream float sums are reproducible). Entry = {atom index in molecule, packed ranges}:
+//     admitted y range in SUBY-voxel slabs (lo | hi << 8) and admitted z range in SUBZ-voxel sub-tiles
+//     (lo << 16 | hi << 24) — all the later slab / sub-tile filters need (D <= 1024). List (b, sx) lives at
+//     xlist[(b*nsx + sx) * xstride]; entry 0 = {count, EMPTY}, entry 1 = {first atom of the molecule, EMPTY}.
+//  B. slab lists: for every slab (sy, zc) of this x-slab the x-list is compacted once more against the slab's
+//     y/z box: slist[slab * SLOTS] = {count, first atom}, then up to SLOTS-1 entries. The voxelize kernel reads
+//     one 512-B line per slab instead of scanning; a count above SLOTS-1 sends that slab to the x-list path.
 constexpr uint32_t EMPTY_ENTRY = 0x00ff00ffu; // y lo = z lo = 255, hi = 0: matches no slab
-constexpr int XL_HEADER = 2; // entry 0 = {count, EMPTY}, entry 1 = {first atom of the molecule, EMPTY}; candidates follow
+constexpr int XL_HEADER = 2;
+constexpr int XL_LDS = 2048; // x-list entries cached in LDS for pass B
+constexpr int SLOTS = 64;    // slab list: header + 63 candidates
 
-__global__ void __launch_bounds__(64) xbin_kernel(const uint4 *bbox, const int64_t *offsets, int nsx, int xstride,
-                                                  uint2 *xlist) {
+__global__ void __launch_bounds__(256)
+    xbin_kernel(const uint4 *__restrict__ bbox, const int64_t *__restrict__ offsets, int nsx, int nsy, int nzc, int NW,
+                int xstride, uint2 *__restrict__ xlist, uint2 *__restrict__ slist) {
+    __shared__ uint2 xs[XL_LDS];
+    __shared__ int wcnt[2][16];
     const int b = blockIdx.x / nsx, sx = blockIdx.x % nsx;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t a0 = offsets[b], a1 = offsets[b + 1];
     const int x0 = SUBX * sx;
     uint2 *dst = xlist + (size_t)blockIdx.x * (size_t)xstride; // fixed stride: addressable from blockIdx alone
-    int count = 0;
-    for (int64_t base = a0; base < a1; base += 64) {
-        const int64_t a = base + lane;
-        bool m = false;
-        uint4 bb = make_uint4(0, 0, 0, 0);
-        if (a < a1) {
-            bb = bbox[a];
-            m = ((int)(bb.x & 0xffff) <= x0 + SUBX - 1) && ((int)(bb.x >> 16) >= x0);
+    int count = 0, phase = 0;
+    for (int64_t base = a0; base < a1; base += 1024, ++phase) {
+        uint4 bb[4];
+        bool m[4];
+        unsigned long long mask[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { // four chunks of 256 atoms in flight
+            const int64_t a = base + u * 256 + tid;
+            bb[u] = (a < a1) ? bbox[a] : make_uint4(0x0000ffffu, 0, 0, 0);
         }
-        const unsigned long long mask = __ballot(m);
-        if (m) {
-            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-            const unsigned packed = ((bb.y & 0xffff) >> SUBY_SH) | (((bb.y >> 16) >> SUBY_SH) << 8) |
-                                    (((bb.z & 0xffff) >> SUBZ_SH) << 16) | (((bb.z >> 16) >> SUBZ_SH) << 24);
-            dst[XL_HEADER + count + below] = make_uint2((unsigned)(a - a0), packed);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            m[u] = ((int)(bb[u].x & 0xffff) <= x0 + SUBX - 1) && ((int)(bb[u].x >> 16) >= x0);
+            mask[u] = __ballot(m[u]);
+            if (lane == 0) wcnt[phase & 1][u * 4 + wave] = __popcll(mask[u]);
         }
-        count += __popcll(mask);
+        __syncthreads();
+        int run = count;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int c = wcnt[phase & 1][u * 4 + w];
+                if (w == wave && m[u]) {
+                    const int pos = run + __builtin_amdgcn_mbcnt_hi((unsigned)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[u], 0u));
+                    const unsigned packed = ((bb[u].y & 0xffff) >> SUBY_SH) | (((bb[u].y >> 16) >> SUBY_SH) << 8) |
+                                            (((bb[u].z & 0xffff) >> SUBZ_SH) << 16) | (((bb[u].z >> 16) >> SUBZ_SH) << 24);
+                    const uint2 en = make_uint2((unsigned)(base + u * 256 + tid - a0), packed);
+                    dst[XL_HEADER + pos] = en;
+                    if (pos < XL_LDS) xs[pos] = en;
+                }
+                run += c;
+            }
+        }
+        count = run;
     }
-    // the header travels with the first entries: the voxelize kernel needs no separate (dependent) scalar loads
-    if (lane == 0) dst[0] = make_uint2((unsigned)count, EMPTY_ENTRY);
-    if (lane == 1) dst[1] = make_uint2((unsigned)(a0 & 0xffffffffll), EMPTY_ENTRY);
+    if (tid == 0) dst[0] = make_uint2((unsigned)count, EMPTY_ENTRY);
+    if (tid == 1) dst[1] = make_uint2((unsigned)a0, EMPTY_ENTRY);
+    __syncthreads();
+
+    const int nslab = nsy * nzc;
+    uint2 *sl_base = slist + (size_t)blockIdx.x * (size_t)nslab * SLOTS;
+    for (int sl = wave; sl < nslab; sl += 4) {
+        const int sy = sl / nzc, zc = sl - sy * nzc;
+        const int zt_lo = zc * NW, zt_hi = zt_lo + NW - 1;
+        uint2 *out = sl_base + (size_t)sl * SLOTS;
+        int n = 0;
+        if (count <= XL_LDS) {
+            for (int i0 = 0; i0 < count; i0 += 64) {
+                const int i = i0 + lane;
+                const uint2 en = xs[i < count ? i : 0];
+                const unsigned pk = (i < count) ? en.y : EMPTY_ENTRY;
+                const bool mm = ((int)(pk & 0xff) <= sy) && ((int)((pk >> 8) & 0xff) >= sy) &&
+                                ((int)((pk >> 16) & 0xff) <= zt_hi) && ((int)(pk >> 24) >= zt_lo);
+                const unsigned long long mk = __ballot(mm);
+                if (mm) {
+                    const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                    if (pos < SLOTS - 1) out[1 + pos] = en;
+                }
+                n += __popcll(mk);
+            }
+        } else {
+            n = SLOTS; // x-list too long for the LDS copy: every slab of this x-slab takes the x-list path
+        }
+        if (lane == 0) out[0] = make_uint2((unsigned)n, (unsigned)a0);
+    }
 }
 
-hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, int32_t xstride, uint2 *xlist,
-                       hipStream_t s) {
+hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
+                       int32_t xstride, uint2 *xlist, uint2 *slist, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(64), 0, s, bbox, offsets, nsx, xstride, xlist);
+    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(256), 0, s, bbox, offsets, nsx, nsy, nzc, NW, xstride,
+                       xlist, slist);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
 // voxelize
 // ------------------------------------------------------------------------------------------------
-// One workgroup = one slab of 4 x 4 x (4*NW) voxels; one wave = one 4^3 sub-tile; one lane = one voxel with
-// CT channel accumulators in registers. grid = (z chunk, sx*nsx + sy, molecule*ncc + channel chunk).
-//   1. scan (wave 0 only, the others wait at the barrier): up to 8 entries per lane of the slab's x-list are
-//      loaded at once (the list sits at a fixed stride, so the loads are in flight while the list length is
-//      still being fetched) and tested against the slab's y/z box; matches are compacted in atom order (ballot +
-//      running count, no cross-wave exchange) into an LDS list;
-//   2. stage: wave w copies the rows of candidates w, w+NW, ... (64-B record + CT channel weights; one coalesced
-//      load each, up to 8 in flight) into LDS; one barrier;
-//   3. walk: each wave picks the candidates whose z range touches its sub-tile (lane-parallel filter + ballot)
-//      and processes them: broadcast LDS reads, fp64 d2 in cdist order, compare with T, exp2, packed FMAs;
+// One workgroup = one slab of SUBX x SUBY x (SUBZ*NW) voxels; one wave = one 64-voxel sub-tile; one lane = one
+// voxel with CT channel accumulators in registers. grid = (slab id, molecule * ncc + channel chunk).
+//   fast path (slab list holds <= min(SLOTS-1, 8*NW) candidates; the normal case):
+//     1. every wave loads the slab's 512-B candidate line (lane l = entry l; lane 0 = {count, first atom});
+//     2. stage: wave w copies the rows of candidates w, w+NW, ... (64-B record + CT channel weights, one
+//        coalesced load each, all in flight at once) into LDS; one barrier;
+//     3. walk: each wave picks the candidates whose z range touches its sub-tile straight from the line it holds
+//        in registers (ballot) and processes them: broadcast LDS reads, fp64 d2 in cdist order, compare with T,
+//        exp2, packed FMAs;
+//   x-list path (more candidates than the line holds; dense clusters): wave 0 compacts the (molecule, x-slab)
+//        list in rounds of LCAP entries into an LDS list, rows are staged in rounds of dcap, same walk;
 //   4. write-out: accumulators -> LDS tile (CR = min(CT,16) channels per round) -> non-temporal 16-B/lane
-//      stores in whole-row runs. Empty slabs skip the LDS round trip.
-// LDS map (dynamic, 16-B aligned), LCAP = 64 * min(NW, 8):
-//   [0, 4*LCAP) int list[] | [4*LCAP, 8*LCAP) uint32 zr[] | [8*LCAP, +16) int nlist |
-//   union { LCAP x SW words of candidate rows ; (CR*16 rows) x RS floats out tile, RS = 4*NW + pad ((RS/4) odd) }
+//      stores in whole-line runs. Empty slabs skip the LDS round trip.
+// LDS map (dynamic, 16-B aligned), LCAP = 64 * min(NW, 4):
+//   [0, 4*LCAP) int list[] | [4*LCAP, 8*LCAP) uint32 zr[] | [8*LCAP, +16) int nlist[] (x-list path only) |
+//   union { dcap x SW words of candidate rows ; (CR*RPC rows) x RS floats out tile }
 
 // 16-B output store. kind 0: plain (line stays in the XCD's L2); 1: nt; 2: sc1 (write-through). Output bytes are
 // written once and never re-read here; nt keeps them from displacing the re-read inputs (0.69 -> 0.54 ms, cfg-2).
@@ -393,7 +448,7 @@ __host__ __device__ __forceinline__ int cand_stride_words(int ct) { return 16 + 
 // candidate rows staged per round: what fits in the out tile's bytes, at least 64, at most the list capacity
 int32_t voxelize_dcap(int32_t ct, int32_t NW) {
     const int cr = ct < 16 ? ct : 16;
-    const int lcap = 64 * (NW < 8 ? NW : 8);
+    const int lcap = 64 * (NW < 4 ? NW : 4);
     const size_t tile = (size_t)cr * RPC * row_stride_floats(NW) * 4;
     int cap = (int)(tile / ((size_t)cand_stride_words(ct) * 4));
     if (cap < 64) cap = 64;
@@ -403,30 +458,28 @@ int32_t voxelize_dcap(int32_t ct, int32_t NW) {
 
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW) {
     const int cr = ct < 16 ? ct : 16;
-    const int lcap = 64 * (NW < 8 ? NW : 8);
+    const int lcap = 64 * (NW < 4 ? NW : 4);
     const size_t tile = (size_t)cr * RPC * row_stride_floats(NW) * 4;
     const size_t cand = (size_t)voxelize_dcap(ct, NW) * cand_stride_words(ct) * 4;
     return (size_t)8 * lcap + 16 + (tile > cand ? tile : cand);
 }
 
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
-__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
+__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     voxelize_kernel(const unsigned *__restrict__ rows, const uint2 *__restrict__ xlist,
-                    const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
-                    const VoxParams P) {
+                    const uint2 *__restrict__ slist, const double *__restrict__ Tc, const float *__restrict__ kc,
+                    float *__restrict__ out, const VoxParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CR = CT < 16 ? CT : 16; // channels per write-out round
     constexpr int NROUND = CT / CR;
-    constexpr int SW = 16 + (CT < 4 ? 4 : CT); // LDS words per candidate (multiple of 4)
+    constexpr int SW = 16 + (CT < 4 ? 4 : CT); // LDS words per candidate row (multiple of 4)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MVX_DIAG
     // diagnostic builds only (MVX_STAMPS): phase time stamps of thread 0 into a buffer nothing else reads
-#ifdef MVX_DIAG
     const size_t blk = blockIdx.x + (size_t)gridDim.x * blockIdx.y;
-#endif
-#ifdef MVX_DIAG
 #define MVX_STAMP(k) \
     if (P.stamps && tid == 0) P.stamps[blk * 8 + (k)] = __builtin_amdgcn_s_memtime();
 #define MVX_ABLATE(bit) (P.ablate & (bit))
@@ -436,54 +489,38 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
 #endif
     MVX_STAMP(0)
     const int NW = P.NW;
-    const int SB = NW < 8 ? NW : 8; // x-list entries per lane and scan round
+    const int SB = NW < 4 ? NW : 4; // x-list entries per lane and scan round (x-list path)
     const int LCAP = 64 * SB;
     const int D = P.D;
 
     int *list = reinterpret_cast<int *>(smem);
     unsigned *zr_l = reinterpret_cast<unsigned *>(smem + 4 * LCAP);
-    int *nlist_s = reinterpret_cast<int *>(smem + 8 * LCAP); // [0] matches of this round, [1] list length, [2] first atom
+    int *nlist_s = reinterpret_cast<int *>(smem + 8 * LCAP);
     unsigned *un = reinterpret_cast<unsigned *>(smem + 8 * LCAP + 16);
     float *tile = reinterpret_cast<float *>(un);
 
     // ---- block -> (molecule * ncc + channel chunk, slab) -------------------------------------------
-    // grid = (T, Z): t = zc + nzc * (sy + nsy * sx) slab id, z = molecule * ncc + chunk. Workgroups are dealt
-    // round-robin over the 8 XCDs in linear order (block L -> XCD L % 8; observed, used for speed only: any
-    // placement gives the same result). With T % 8 == 0 the XCD is t % 8, so swapping the low three bits of t
-    // and z makes XCD k work through all slabs of molecule (z & ~7) + k: its rows and x-lists are then pulled
-    // into ONE L2 instead of eight. Bijective on z < 8 * (Z / 8); the tail keeps the identity.
+    // grid = (T, Z): t = zc + nzc * (sy + nsy * sx) slab id, z = molecule * ncc + chunk. (MVX_XCD_SWAP=1 swaps the
+    // low three bits of t and z so that XCD k works through whole molecules; measured slower, kept as a knob.)
     unsigned t = blockIdx.x, z = blockIdx.y;
     if (P.xcd_swap && z < (gridDim.y & ~7u)) {
         const unsigned tl = t & 7u, zl = z & 7u;
         t = (t & ~7u) | zl;
         z = (z & ~7u) | tl;
     }
-    const unsigned ty = (P.nzc == 1) ? t : __umulhi(t, P.nzc_inv); // t / nzc
-    const int zc = (int)(t - ty * P.nzc);
-    const int sx = (P.nsy == 1) ? (int)ty : (int)__umulhi(ty, P.nsy_inv); // ty / nsy
-    const int sy = (int)ty - sx * P.nsy;
     int b = (int)z, cc = 0;
     if (P.ncc > 1) {
         b = (int)z / P.ncc;
         cc = (int)z - b * P.ncc;
     }
+    // the slab's candidate line: {count, first atom}, then {atom index, packed ranges} per candidate
+    const uint2 E = slist[((size_t)b * (size_t)gridDim.x + t) * SLOTS + lane];
+    const unsigned ty = (P.nzc == 1) ? t : __umulhi(t, P.nzc_inv); // t / nzc
+    const int zc = (int)(t - ty * P.nzc);
+    const int sx = (P.nsy == 1) ? (int)ty : (int)__umulhi(ty, P.nsy_inv); // ty / nsy
+    const int sy = (int)ty - sx * P.nsy;
     const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
     const int zt_lo = zc * NW, zt_hi = zt_lo + NW - 1; // sub-tile index range of the slab along z
-    // x-list of (b, sx): fixed-stride region whose first two entries carry the list length and the molecule's
-    // first atom, so nothing here waits for a dependent scalar load
-    const uint2 *__restrict__ xl = xlist + ((size_t)b * P.nsx + sx) * (size_t)P.xstride;
-    const uint2 kEmpty = make_uint2(0u, EMPTY_ENTRY);
-    uint2 e[8];
-    if (wave == 0) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = u * 64 + lane;
-            e[u] = (u < SB && i < P.xstride) ? xl[i] : kEmpty;
-        }
-        // header -> LDS for the other waves (they read it after the first barrier)
-        if (lane == 0) nlist_s[1] = MVX_ABLATE(2) ? XL_HEADER : (int)e[0].x + XL_HEADER;
-        if (lane == 1) nlist_s[2] = (int)e[0].x;
-    }
     MVX_STAMP(1)
 
     // ---- this lane's voxel ---------------------------------------------------------------------
@@ -497,137 +534,135 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 6 : 4))
     const int lane_word = lane < 16 ? lane : lane + cc * CT;
     const bool stager = lane < 16 + CT;
 
-    bool any_candidate = false;
-    int nx = 0; // entries incl. header, published with the first round's list
-    int64_t a0 = 0;
     float2v acc[(CT + 1) / 2];
-
-    // ---- 1. wave 0: ordered compaction of up to LCAP x-list entries [base, ...) against the slab's y/z box.
-    // Round 0 consumes the entries already sitting in registers; the accumulators are not live yet, which keeps
-    // the prefetched entries out of scratch.
-    auto scan_round = [&](int base, int nxe, bool from_regs) {
-        int n = 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (u < SB) {
-                const int i = base + u * 64 + lane;
-                uint2 en = e[u];
-                if (!from_regs) en = (i < nxe) ? xl[i] : kEmpty;
-                // packed slab ranges: y lo | y hi << 8 | z sub-tile lo << 16 | z sub-tile hi << 24
-                // (the two header entries carry EMPTY_ENTRY and never match)
-                const bool m = (i < nxe) && ((int)(en.y & 0xff) <= sy) && ((int)((en.y >> 8) & 0xff) >= sy) &&
-                               ((int)((en.y >> 16) & 0xff) <= zt_hi) && ((int)(en.y >> 24) >= zt_lo);
-                const unsigned long long mask = __ballot(m);
-                if (m) {
-                    const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    list[pos] = (int)en.x;
-                    zr_l[pos] = en.y;
-                }
-                n += __popcll(mask);
+    for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
+
+    // one candidate: row r staged in LDS
+    auto accumulate = [&](const unsigned *r) {
+        const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
+        const double2 PzT = *reinterpret_cast<const double2 *>(r + 4); // pz, T
+        const uint4 q = *reinterpret_cast<const uint4 *>(r + 8);       // k, type, xr, yr
+        const double dx = Pxy.x - gx, dy = Pxy.y - gy, dz = PzT.x - gz;
+        const double d2 = (dx * dx + dy * dy) + dz * dz; // cdist order, no fma
+        bool hit = d2 <= PzT.y;
+        if (LANE_RANGE) {
+            const unsigned zr = r[12];
+            hit = hit && (ix >= (int)(q.z & 0xffff)) && (ix <= (int)(q.z >> 16)) && (iy >= (int)(q.w & 0xffff)) &&
+                  (iy <= (int)(q.w >> 16)) && (iz >= (int)(zr & 0xffff)) && (iz <= (int)(zr >> 16));
+        }
+        const float d2f = (float)d2;
+        const float *f = reinterpret_cast<const float *>(r + 16);
+        float val = 0.0f;
+        if (!CHANWISE) {
+            const float ev = GAUSS ? __builtin_amdgcn_exp2f(__uint_as_float(q.x) * d2f) : 1.0f;
+            val = hit ? ev : 0.0f;
+        }
+        if constexpr (CHANWISE) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int ch = (cc * CT + c < P.C) ? cc * CT + c : P.C - 1;
+                const float ev = GAUSS ? __builtin_amdgcn_exp2f(kc[ch] * d2f) : 1.0f;
+                const float vc = (hit && d2 <= Tc[ch]) ? ev : 0.0f;
+                if (c & 1) acc[c / 2].y = fmaf(vc, f[c], acc[c / 2].y);
+                else acc[c / 2].x = fmaf(vc, f[c], acc[c / 2].x);
+            }
+        } else if constexpr (CT == 1) {
+            acc[0].x = fmaf(val, f[0], acc[0].x);
+        } else {
+            const float2v v2 = (float2v){val, val};
+#pragma unroll
+            for (int c = 0; c < CT / 2; ++c) {
+                const float2v f2 = *reinterpret_cast<const float2v *>(f + 2 * c);
+                acc[c] = __builtin_elementwise_fma(v2, f2, acc[c]);
             }
         }
-        if (lane == 0) nlist_s[0] = n;
     };
 
-    // ---- 2./3. stage the listed rows in rounds of dcap and walk them ------------------------------------
-    auto process_list = [&](int nl) {
-        for (int c0 = 0; c0 < nl; c0 += P.dcap) {
-            const int n = (nl - c0) < P.dcap ? (nl - c0) : P.dcap; // rows staged this round
-            if (c0 > 0) __syncthreads(); // previous round's rows consumed
-            any_candidate = true;
-            // stage rows: lanes 0-15 the 64-B record, lanes 16..16+CT-1 the channel weights
-            for (int j0 = wave; j0 < n; j0 += 8 * NW) {
-                unsigned v[8];
+    const int n_line = MVX_ABLATE(2) ? 0 : __builtin_amdgcn_readlane((int)E.x, 0);
+    const int64_t a0 = (int64_t)(unsigned)__builtin_amdgcn_readlane((int)E.y, 0);
+    const int fast_cap = (SLOTS - 1) < 8 * NW ? (SLOTS - 1) : 8 * NW;
+    bool any_candidate = n_line > 0;
+    if (n_line <= fast_cap) {
+        // ---- fast path -------------------------------------------------------------------------------
+        if (n_line > 0) {
+            unsigned v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int j = j0 + u * NW;
-                    v[u] = 0u;
-                    if (j < n && stager) v[u] = rows[(size_t)(a0 + list[c0 + j]) * (size_t)P.row_words + lane_word];
+            for (int u = 0; u < 8; ++u) {
+                const int j = wave + u * NW; // candidate staged by this wave (wave-uniform)
+                v[u] = 0u;
+                if (j < n_line) {
+                    const int ai = __builtin_amdgcn_readlane((int)E.x, j + 1);
+                    if (stager) v[u] = rows[(size_t)(a0 + ai) * (size_t)P.row_words + lane_word];
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int j = j0 + u * NW;
-                    if (j < n && stager) un[j * SW + lane] = v[u];
-                }
+            for (int u = 0; u < 8; ++u) {
+                const int j = wave + u * NW;
+                if (j < n_line && stager) un[j * SW + lane] = v[u];
             }
             __syncthreads();
             MVX_STAMP(3)
-
-            // walk the candidates that touch this wave's sub-tile
-            for (int jb = 0; jb < (MVX_ABLATE(1) ? 0 : n); jb += 64) {
-                const int j = jb + lane;
-                bool ok = false;
-                if (j < n) {
-                    const unsigned zr = zr_l[c0 + j];
-                    ok = ((int)((zr >> 16) & 0xff) <= zt_w) && ((int)(zr >> 24) >= zt_w);
-                }
+            if (!MVX_ABLATE(1)) {
+                const unsigned pk = E.y;
+                const bool ok = (lane >= 1) && (lane <= n_line) && ((int)((pk >> 16) & 0xff) <= zt_w) && ((int)(pk >> 24) >= zt_w);
                 unsigned long long mask = __ballot(ok);
                 while (mask) {
-                    const int jj = jb + __builtin_ctzll(mask);
+                    const int jj = __builtin_ctzll(mask) - 1;
                     mask &= mask - 1;
-                    const unsigned *r = un + jj * SW;
-                    const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
-                    const double2 PzT = *reinterpret_cast<const double2 *>(r + 4); // pz, T
-                    const uint4 q = *reinterpret_cast<const uint4 *>(r + 8);       // k, type, xr, yr
-                    const double dx = Pxy.x - gx, dy = Pxy.y - gy, dz = PzT.x - gz;
-                    const double d2 = (dx * dx + dy * dy) + dz * dz; // cdist order, no fma
-                    bool hit = d2 <= PzT.y;
-                    if (LANE_RANGE) {
-                        const unsigned zr = r[12];
-                        hit = hit && (ix >= (int)(q.z & 0xffff)) && (ix <= (int)(q.z >> 16)) &&
-                              (iy >= (int)(q.w & 0xffff)) && (iy <= (int)(q.w >> 16)) && (iz >= (int)(zr & 0xffff)) &&
-                              (iz <= (int)(zr >> 16));
-                    }
-                    const float d2f = (float)d2;
-                    const float *f = reinterpret_cast<const float *>(r + 16);
-                    float val = 0.0f;
-                    if (!CHANWISE) {
-                        const float ev = GAUSS ? __builtin_amdgcn_exp2f(__uint_as_float(q.x) * d2f) : 1.0f;
-                        val = hit ? ev : 0.0f;
-                    }
-                    if constexpr (CHANWISE) {
-#pragma unroll
-                        for (int c = 0; c < CT; ++c) {
-                            const int ch = (cc * CT + c < P.C) ? cc * CT + c : P.C - 1;
-                            const float ev = GAUSS ? __builtin_amdgcn_exp2f(kc[ch] * d2f) : 1.0f;
-                            const float vc = (hit && d2 <= Tc[ch]) ? ev : 0.0f;
-                            if (c & 1) acc[c / 2].y = fmaf(vc, f[c], acc[c / 2].y);
-                            else acc[c / 2].x = fmaf(vc, f[c], acc[c / 2].x);
-                        }
-                    } else if constexpr (CT == 1) {
-                        acc[0].x = fmaf(val, f[0], acc[0].x);
-                    } else {
-                        const float2v v2 = (float2v){val, val};
-#pragma unroll
-                        for (int c = 0; c < CT / 2; ++c) {
-                            const float2v f2 = *reinterpret_cast<const float2v *>(f + 2 * c);
-                            acc[c] = __builtin_elementwise_fma(v2, f2, acc[c]);
-                        }
-                    }
+                    accumulate(un + jj * SW);
                 }
             }
             MVX_STAMP(4)
         }
-    };
-
-    // round 0: entries prefetched in registers
-    if (wave == 0) {
-        const int nxw = __builtin_amdgcn_readlane((int)e[0].x, 0) + XL_HEADER;
-        scan_round(0, MVX_ABLATE(2) ? XL_HEADER : nxw, true);
-    }
-    __syncthreads(); // list complete
-    nx = nlist_s[1];
-    a0 = (int64_t)(unsigned)nlist_s[2];
-    MVX_STAMP(2)
-#pragma unroll
-    for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
-    process_list(nlist_s[0]);
-    // further rounds (x-lists longer than LCAP entries: dense x-slabs), nothing prefetched
-    for (int base = LCAP; base < nx; base += LCAP) {
-        __syncthreads(); // list / candidate rows of the previous round consumed
-        if (wave == 0) scan_round(base, nx, false);
-        __syncthreads();
-        process_list(nlist_s[0]);
+    } else {
+        // ---- x-list path: more candidates than the slab line holds ---------------------------------------
+        const uint2 *__restrict__ xl = xlist + ((size_t)b * P.nsx + sx) * (size_t)P.xstride;
+        const int nx = (int)xl[0].x + XL_HEADER;
+        for (int base = 0; base < nx; base += LCAP) {
+            if (base > 0) __syncthreads(); // list / candidate rows of the previous round consumed
+            if (wave == 0) { // ordered compaction of LCAP entries against the slab's y/z box
+                int n = 0;
+                for (int u = 0; u < SB; ++u) {
+                    const int i = base + u * 64 + lane;
+                    const uint2 en = (i < nx) ? xl[i] : make_uint2(0u, EMPTY_ENTRY);
+                    // (the two header entries carry EMPTY_ENTRY and never match)
+                    const bool m = ((int)(en.y & 0xff) <= sy) && ((int)((en.y >> 8) & 0xff) >= sy) &&
+                                   ((int)((en.y >> 16) & 0xff) <= zt_hi) && ((int)(en.y >> 24) >= zt_lo);
+                    const unsigned long long mask = __ballot(m);
+                    if (m) {
+                        const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        list[pos] = (int)en.x;
+                        zr_l[pos] = en.y;
+                    }
+                    n += __popcll(mask);
+                }
+                if (lane == 0) nlist_s[0] = n;
+            }
+            __syncthreads();
+            const int nl = nlist_s[0];
+            for (int c0 = 0; c0 < nl; c0 += P.dcap) {
+                const int n = (nl - c0) < P.dcap ? (nl - c0) : P.dcap; // rows staged this round
+                if (c0 > 0) __syncthreads();
+                for (int j = wave; j < n; j += NW)
+                    if (stager) un[j * SW + lane] = rows[(size_t)(a0 + list[c0 + j]) * (size_t)P.row_words + lane_word];
+                __syncthreads();
+                for (int jb = 0; jb < n; jb += 64) {
+                    const int j = jb + lane;
+                    bool ok = false;
+                    if (j < n) {
+                        const unsigned zr = zr_l[c0 + j];
+                        ok = ((int)((zr >> 16) & 0xff) <= zt_w) && ((int)(zr >> 24) >= zt_w);
+                    }
+                    unsigned long long mask = __ballot(ok);
+                    while (mask) {
+                        const int jj = jb + __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        accumulate(un + jj * SW);
+                    }
+                }
+            }
+        }
     }
 
     // ---- 4. write-out ----------------------------------------------------------------------------
@@ -757,7 +792,7 @@ struct LaunchFn {
         }
         hipLaunchKernelGGL((voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>),
                            dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(p.B * p.ncc)), dim3(p.NW * 64), lds, s, a.rows,
-                           a.xlist, a.Tc, a.kc, a.out, a.p);
+                           a.xlist, a.slist, a.Tc, a.kc, a.out, a.p);
         return hipGetLastError();
     }
 };
