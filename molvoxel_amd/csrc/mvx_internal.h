@@ -7,10 +7,11 @@
 
 namespace mvx {
 
-// Sub-tile owned by one wave (one voxel per lane): SUBX x SUBY x SUBZ = 64 voxels. 4^3 is the most compact shape
-// (Minkowski volume with a radius-2-voxel ball: 440 voxels; 497 for 2 x 4 x 8; 1442 for 1 x 1 x 64), i.e. the fewest
-// candidate atoms per wave. Measured on cfg-2: 4x4x4 with 128-B runs 0.48 ms, 2x4x8 with whole 256-B rows 0.50 ms.
-constexpr int SUBX_SH = 2, SUBY_SH = 2, SUBZ_SH = 2;
+// Sub-tile owned by one wave (one voxel per lane): SUBX x SUBY x SUBZ = 64 voxels. 2 x 4 x 8 keeps the footprint
+// compact (Minkowski volume with a radius-2-voxel ball: 497 voxels; 440 for 4^3; 1442 for 1 x 1 x 64) while eight
+// waves side by side along z cover whole 256-B rows at D = 64 (4 y-rows of one (channel, x) plane = 1 KiB
+// contiguous). Measured on cfg-2 with the slab-line kernel: 2x4x8 0.400 ms, 4x4x4 (128-B runs) 0.415 ms.
+constexpr int SUBX_SH = 1, SUBY_SH = 2, SUBZ_SH = 3;
 constexpr int SUBX = 1 << SUBX_SH, SUBY = 1 << SUBY_SH, SUBZ = 1 << SUBZ_SH;
 static_assert(SUBX * SUBY * SUBZ == 64, "one voxel per lane");
 constexpr int RPC = SUBX * SUBY; // tile rows per channel
