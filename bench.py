@@ -112,19 +112,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    # one GPU per rank is the real layout; with fewer GPUs than ranks (rehearsal on a 1-GPU box) ranks share devices
+    # and the barrier runs over gloo, because RCCL refuses two ranks on one device
+    dev_index = local_rank if ndev >= world else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if ndev >= world:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import molvoxel_amd
 
     B = args.batch
     wl, coords, feats = make_batch(B, rank)
-    vox = molvoxel_amd.create_voxelizer(0.5, 64, "scalar", "gaussian", library="hip", device=local_rank)
+    vox = molvoxel_amd.create_voxelizer(0.5, 64, "scalar", "gaussian", library="hip", device=dev_index)
     offsets = np.arange(B + 1, dtype=np.int64) * 4000
     d_coords = vox.asarray(np.concatenate(coords), "coords")
     d_feats = vox.asarray(np.concatenate(feats), "features")
@@ -152,7 +159,7 @@ def main():
     vox.set_profiling(False)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -323,7 +323,7 @@ constexpr int SLOTS = 64;    // slab list: header + 63 candidates
 
 __global__ void __launch_bounds__(256)
     xbin_kernel(const uint4 *__restrict__ bbox, const int64_t *__restrict__ offsets, int nsx, int nsy, int nzc, int NW,
-                int xstride, uint2 *__restrict__ xlist, uint2 *__restrict__ slist) {
+                int xstride, uint2 *__restrict__ xlist, uint2 *__restrict__ slist, int ablate) {
     __shared__ uint2 xs[XL_LDS];
     __shared__ int wcnt[2][16];
     const int b = blockIdx.x / nsx, sx = blockIdx.x % nsx;
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256)
     const int x0 = SUBX * sx;
     uint2 *dst = xlist + (size_t)blockIdx.x * (size_t)xstride; // fixed stride: addressable from blockIdx alone
     int count = 0, phase = 0;
-    for (int64_t base = a0; base < a1; base += 1024, ++phase) {
+    for (int64_t base = a0; base < ((ablate & 16) ? a0 : a1); base += 1024, ++phase) {
         uint4 bb[4];
         bool m[4];
         unsigned long long mask[4];
@@ -371,6 +371,7 @@ __global__ void __launch_bounds__(256)
     if (tid == 1) dst[1] = make_uint2((unsigned)a0, EMPTY_ENTRY);
     __syncthreads();
 
+    if (ablate & 8) return;
     const int nslab = nsy * nzc;
     uint2 *sl_base = slist + (size_t)blockIdx.x * (size_t)nslab * SLOTS;
     for (int sl = wave; sl < nslab; sl += 4) {
@@ -402,8 +403,9 @@ __global__ void __launch_bounds__(256)
 hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
                        int32_t xstride, uint2 *xlist, uint2 *slist, hipStream_t s) {
     if (B <= 0) return hipSuccess;
+    static const int ablate = std::getenv("MVX_XBIN_ABLATE") ? std::atoi(std::getenv("MVX_XBIN_ABLATE")) : 0;
     hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(256), 0, s, bbox, offsets, nsx, nsy, nzc, NW, xstride,
-                       xlist, slist);
+                       xlist, slist, ablate);
     return hipGetLastError();
 }
 
