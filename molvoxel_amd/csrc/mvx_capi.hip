@@ -259,7 +259,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     const int row_words = 16 + Cpad;
     if ((rc = ensure(h->rec, n_alloc * (size_t)row_words * 4))) return rc;
     h->row_bytes = row_words * 4;
-    if ((rc = ensure(h->bbox, n_alloc * sizeof(uint4)))) return rc;
+    if ((rc = ensure(h->bbox, n_alloc * (sizeof(uint4) + sizeof(unsigned))))) return rc; // ranges + x ranges (SoA)
 
     const bool gauss = (h->cfg.density == MVX_GAUSSIAN);
     const bool chanwise = (r.radii_type == MVX_RADII_CHANNEL && r.mode == MODE_FEATURES);
@@ -280,6 +280,9 @@ int run(mvx_handle *h, const RunArgs &r) {
     pa.coords = d_coords;
     pa.radii = d_radii;
     pa.types = (r.mode == MODE_TYPES) ? reinterpret_cast<const int32_t *>(d_chan) : nullptr;
+    pa.features = (r.mode == MODE_FEATURES) ? reinterpret_cast<const float *>(d_chan) : nullptr;
+    pa.mode = r.mode;
+    pa.Cpad = Cpad;
     pa.offsets = d_off;
     pa.xforms = d_xf;
     pa.chan_aux = d_rmax;
@@ -296,10 +299,8 @@ int run(mvx_handle *h, const RunArgs &r) {
     pa.rows = reinterpret_cast<char *>(h->rec.p);
     pa.row_bytes = row_words * 4;
     pa.bbox = reinterpret_cast<uint4 *>(h->bbox.p);
+    pa.xr = reinterpret_cast<unsigned *>(reinterpret_cast<uint4 *>(h->bbox.p) + n_alloc);
     HIP_TRY(launch_prep(pa, s));
-    HIP_TRY(launch_pack_channels(reinterpret_cast<float *>(h->rec.p), row_words, Cpad, r.C, r.mode,
-                                 (r.mode == MODE_FEATURES) ? reinterpret_cast<const float *>(d_chan) : nullptr,
-                                 (r.mode == MODE_TYPES) ? reinterpret_cast<const int32_t *>(d_chan) : nullptr, total, s));
 
     // ---- voxelize ---------------------------------------------------------------------------------
     VoxArgs va;
@@ -341,7 +342,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     const int64_t xstride = nmax + 2; // two header entries per list
     if ((rc = ensure(h->xlist, (size_t)r.B * nsx * (size_t)xstride * sizeof(uint2)))) return rc;
     if ((rc = ensure(h->xcount, (size_t)r.B * nsx * nsy * nzc * 64 * sizeof(uint2)))) return rc; // slab lines
-    HIP_TRY(launch_xbin(pa.bbox, d_off, r.B, nsx, nsy, nzc, NW, (int32_t)xstride, reinterpret_cast<uint2 *>(h->xlist.p),
+    HIP_TRY(launch_xbin(pa.bbox, pa.xr, d_off, r.B, nsx, nsy, nzc, NW, (int32_t)xstride, reinterpret_cast<uint2 *>(h->xlist.p),
                         reinterpret_cast<uint2 *>(h->xcount.p), s));
     va.slist = reinterpret_cast<const uint2 *>(h->xcount.p);
     va.p.xstride = (int32_t)xstride;

@@ -45,6 +45,9 @@ struct PrepArgs {
     const double *coords;   // (total, 3)
     const float *radii;     // per RadiiSrc
     const int32_t *types;   // (total,) or null
+    const float *features;  // (total, C) or null
+    int32_t mode;           // Mode: which channel weights go behind the records
+    int32_t Cpad;           // channel weights per row (zero padded)
     const int64_t *offsets; // device, B + 1
     const mvx_xform *xforms; // device, B records, or null
     const float *chan_aux;  // device: [0] = max channel radius (float32) for RAD_CHANNEL_FEATURES
@@ -58,7 +61,8 @@ struct PrepArgs {
     Geom g;
     char *rows;        // per-atom rows: [AtomRec 64 B | Cpad channel weights]
     int32_t row_bytes; // 64 + 4 * Cpad
-    uint4 *bbox;       // {xr, yr, zr, 0} copy of the ranges, SoA for the x-slab binning
+    uint4 *bbox;       // {xr, yr, zr, 0} copy of the ranges for the binning pass
+    unsigned *xr;      // admitted x ranges alone (4 B per atom): what every x-slab block of the binning pass scans
 };
 
 struct VoxParams { // by-value kernel parameters (scalars only: pointers are separate __restrict__ arguments)
@@ -91,7 +95,7 @@ struct VoxArgs {
 hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax,
                            double *Tc, float *kc, hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
-hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
+hipError_t launch_xbin(const uint4 *bbox, const unsigned *xr, const int64_t *offsets, int32_t B, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
                        int32_t xstride, uint2 *xlist, uint2 *slist, hipStream_t s);
 hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf_dev, double *out, hipStream_t s);
 // ct: channels per thread (1, 4, 8, 16, 32); lane_range: per-lane index-range check needed
@@ -99,7 +103,5 @@ hipError_t launch_voxelize(const VoxArgs &a, int32_t ct, bool gauss, bool chanwi
 hipError_t configure_kernels(); // raises the dynamic-LDS limit of every instantiation
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW);
 int32_t voxelize_dcap(int32_t ct, int32_t NW);
-hipError_t launch_pack_channels(float *rows, int32_t row_words, int32_t Cpad, int32_t C, int32_t mode,
-                                const float *features, const int32_t *types, int64_t total, hipStream_t s);
 
 } // namespace mvx

@@ -164,8 +164,36 @@ __device__ __forceinline__ void block_interval(const Geom &g, double p, double r
 // lo = 0xffff, hi = 0: fails every overlap test (lo <= box_hi needs box_hi >= 65535, beyond any grid)
 constexpr uint32_t EMPTY_RANGE = 0x0000ffffu;
 
+// Also writes the channel weights behind each record (features / one-hot type / 1, zero padded to Cpad): the
+// block copies the weights of its 256 atoms cooperatively, coalesced on the source side.
 __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
     const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    {   // channel weights of atoms [blockIdx.x * 256, +256)
+        const int64_t first = (int64_t)blockIdx.x * 256;
+        const int nat = (int)((A.total - first) < 256 ? (A.total - first) : 256);
+        const int row_words = A.row_bytes / 4;
+        float *rows = reinterpret_cast<float *>(A.rows) + first * row_words + 16;
+        if (A.mode == MODE_FEATURES && A.C == A.Cpad && (A.Cpad & 3) == 0) {
+            // the block's weights are one contiguous run of nat * C floats: 16-B copies, 32-bit index math
+            const int q4 = A.Cpad >> 2;
+            const float4 *src = reinterpret_cast<const float4 *>(A.features + first * A.C);
+            for (int i = threadIdx.x; i < nat * q4; i += 256) {
+                const int al = i / q4, c4 = i - al * q4;
+                *reinterpret_cast<float4 *>(rows + (size_t)al * row_words + 4 * c4) = src[i];
+            }
+        } else {
+            for (int i = threadIdx.x; i < nat * A.Cpad; i += 256) {
+                const int al = i / A.Cpad, c = i - al * A.Cpad;
+                float f = 0.0f;
+                if (c < A.C) {
+                    if (A.mode == MODE_FEATURES) f = A.features[(first + al) * A.C + c];
+                    else if (A.mode == MODE_TYPES) f = (A.types[first + al] == c) ? 1.0f : 0.0f;
+                    else f = 1.0f;
+                }
+                rows[(size_t)al * row_words + c] = f;
+            }
+        }
+    }
     if (a >= A.total) return;
     const int b = find_molecule(A.offsets, A.B, a);
     double p[3] = {A.coords[3 * a], A.coords[3 * a + 1], A.coords[3 * a + 2]};
@@ -247,6 +275,7 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
     R.zr = rng[2];
     *reinterpret_cast<AtomRec *>(A.rows + (size_t)a * A.row_bytes) = R; // row = 64-B record + padded channel weights
     A.bbox[a] = make_uint4(rng[0], rng[1], rng[2], 0u);
+    A.xr[a] = rng[0];
 }
 
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s) {
@@ -274,37 +303,6 @@ hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf
 }
 
 // ------------------------------------------------------------------------------------------------
-// channel weights: features / one-hot types / ones, padded with zeros, behind each atom's record
-// ------------------------------------------------------------------------------------------------
-// Row a = [AtomRec 64 B | Cpad floats]. forward_features copies F[a, :] (numpy/voxelizer.py:233: out = F^T @ res),
-// forward_types writes the one-hot of types[a] (out[type] += res, :364-365), forward_single a single 1 (:476).
-// The voxelize kernel then reads one contiguous row per candidate whatever the operator was.
-__global__ void __launch_bounds__(256)
-    pack_channels_kernel(float *rows, int row_words, int Cpad, int C, int mode, const float *__restrict__ features,
-                         const int32_t *__restrict__ types, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total * Cpad) return;
-    const int64_t a = idx / Cpad;
-    const int c = (int)(idx - a * Cpad);
-    float f = 0.0f;
-    if (c < C) {
-        if (mode == MODE_FEATURES) f = features[a * C + c];
-        else if (mode == MODE_TYPES) f = (types[a] == c) ? 1.0f : 0.0f;
-        else f = 1.0f;
-    }
-    rows[a * row_words + 16 + c] = f;
-}
-
-hipError_t launch_pack_channels(float *rows, int32_t row_words, int32_t Cpad, int32_t C, int32_t mode,
-                                const float *features, const int32_t *types, int64_t total, hipStream_t s) {
-    if (total <= 0) return hipSuccess;
-    const int64_t n = total * Cpad;
-    hipLaunchKernelGGL(pack_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, row_words, Cpad, C,
-                       mode, features, types, total);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
 // binning: ordered x-slab lists and per-slab candidate lists
 // ------------------------------------------------------------------------------------------------
 // One 256-thread block per (molecule, SUBX-voxel x-slab).
@@ -322,7 +320,7 @@ constexpr int XL_LDS = 2048; // x-list entries cached in LDS for pass B
 constexpr int SLOTS = 64;    // slab list: header + 63 candidates
 
 __global__ void __launch_bounds__(256)
-    xbin_kernel(const uint4 *__restrict__ bbox, const int64_t *__restrict__ offsets, int nsx, int nsy, int nzc, int NW,
+    xbin_kernel(const uint4 *__restrict__ bbox, const unsigned *__restrict__ xr, const int64_t *__restrict__ offsets, int nsx, int nsy, int nzc, int NW,
                 int xstride, uint2 *__restrict__ xlist, uint2 *__restrict__ slist, int ablate) {
     __shared__ uint2 xs[XL_LDS];
     __shared__ int wcnt[2][16];
@@ -333,17 +331,17 @@ __global__ void __launch_bounds__(256)
     uint2 *dst = xlist + (size_t)blockIdx.x * (size_t)xstride; // fixed stride: addressable from blockIdx alone
     int count = 0, phase = 0;
     for (int64_t base = a0; base < ((ablate & 16) ? a0 : a1); base += 1024, ++phase) {
-        uint4 bb[4];
+        unsigned xv[4]; // admitted x ranges (SoA: 4 B per atom); y/z ranges are fetched for matches only
         bool m[4];
         unsigned long long mask[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { // four chunks of 256 atoms in flight
             const int64_t a = base + u * 256 + tid;
-            bb[u] = (a < a1) ? bbox[a] : make_uint4(0x0000ffffu, 0, 0, 0);
+            xv[u] = (a < a1) ? xr[a] : 0x0000ffffu;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            m[u] = ((int)(bb[u].x & 0xffff) <= x0 + SUBX - 1) && ((int)(bb[u].x >> 16) >= x0);
+            m[u] = ((int)(xv[u] & 0xffff) <= x0 + SUBX - 1) && ((int)(xv[u] >> 16) >= x0);
             mask[u] = __ballot(m[u]);
             if (lane == 0) wcnt[phase & 1][u * 4 + wave] = __popcll(mask[u]);
         }
@@ -356,8 +354,9 @@ __global__ void __launch_bounds__(256)
                 const int c = wcnt[phase & 1][u * 4 + w];
                 if (w == wave && m[u]) {
                     const int pos = run + __builtin_amdgcn_mbcnt_hi((unsigned)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[u], 0u));
-                    const unsigned packed = ((bb[u].y & 0xffff) >> SUBY_SH) | (((bb[u].y >> 16) >> SUBY_SH) << 8) |
-                                            (((bb[u].z & 0xffff) >> SUBZ_SH) << 16) | (((bb[u].z >> 16) >> SUBZ_SH) << 24);
+                    const uint4 bb = bbox[base + u * 256 + tid];
+                    const unsigned packed = ((bb.y & 0xffff) >> SUBY_SH) | (((bb.y >> 16) >> SUBY_SH) << 8) |
+                                            (((bb.z & 0xffff) >> SUBZ_SH) << 16) | (((bb.z >> 16) >> SUBZ_SH) << 24);
                     const uint2 en = make_uint2((unsigned)(base + u * 256 + tid - a0), packed);
                     dst[XL_HEADER + pos] = en;
                     if (pos < XL_LDS) xs[pos] = en;
@@ -400,11 +399,11 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-hipError_t launch_xbin(const uint4 *bbox, const int64_t *offsets, int32_t B, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
+hipError_t launch_xbin(const uint4 *bbox, const unsigned *xr, const int64_t *offsets, int32_t B, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
                        int32_t xstride, uint2 *xlist, uint2 *slist, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     static const int ablate = std::getenv("MVX_XBIN_ABLATE") ? std::atoi(std::getenv("MVX_XBIN_ABLATE")) : 0;
-    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(256), 0, s, bbox, offsets, nsx, nsy, nzc, NW, xstride,
+    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(256), 0, s, bbox, xr, offsets, nsx, nsy, nzc, NW, xstride,
                        xlist, slist, ablate);
     return hipGetLastError();
 }
