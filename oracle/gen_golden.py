@@ -14,6 +14,7 @@ Writes:
   tests/golden/pointcloud_10gs.npz   heavy-atom point clouds parsed from the reference's test/10gs data
   tests/golden/transform_cases.npz   seeded random-transform cases (np.random.seed -> coords out)
   tests/golden/api_cases.npz     end-to-end Voxelizer.forward calls through the reference's public API
+  tests/golden/dx_cases.npz      OpenDX dumps written by the reference's dx.py
 """
 from __future__ import annotations
 
@@ -272,6 +273,29 @@ def gen_api(molvoxel, pc):
     print("api_cases:", len(index))
 
 
+def gen_dx(ref_root):
+    """DX text dumps written by the reference's own writer. molvoxel/etc/pymol/__init__.py needs PyMOL, so dx.py is
+    loaded on its own from its file."""
+    import importlib.util
+    import tempfile
+
+    spec = importlib.util.spec_from_file_location("ref_dx", os.path.join(ref_root, "molvoxel", "etc", "pymol", "dx.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(3)
+    cases = {}
+    for name, shape, res, cen in [("a", (4, 5, 6), 0.5, (1.0, -2.5, 3.25)), ("b", (3, 3, 3), 0.4, (0.0, 0.0, 0.0)),
+                                  ("c", (2, 2, 5), 0.75, (10.0, 20.0, -30.0))]:
+        v = (rng.random(shape) * 3 - 1).astype(np.float32)
+        with tempfile.NamedTemporaryFile("r", suffix=".dx") as tf:
+            mod.write_grid_to_dx_file(tf.name, v, cen, res)
+            txt = open(tf.name).read()
+        cases[f"{name}/values"], cases[f"{name}/center"] = v, np.array(cen)
+        cases[f"{name}/resolution"], cases[f"{name}/text"] = np.array(res), np.array(txt)
+    np.savez_compressed(os.path.join(GOLD, "dx_cases.npz"), **cases)
+    print("dx_cases:", len(cases) // 4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -310,6 +334,8 @@ def main():
         gen_transforms(molvoxel)
     if not only or "api" in only:
         gen_api(molvoxel, pc)
+    if not only or "dx" in only:
+        gen_dx(args.ref)
 
 
 if __name__ == "__main__":
