@@ -57,7 +57,7 @@ struct mvx_handle {
     Geom g;
     float sigma32;
     int device;
-    DevBuf rec, bbox, xlist, xcount, meta, aux, in_coords, in_chan, in_radii, out_stage;
+    DevBuf rec, bbox, xlist, slist, meta, aux, in_coords, in_chan, in_radii, out_stage;
     PinnedSlot slots[NSLOTS];
     int next_slot = 0;
     std::vector<hipEvent_t> ev; // 2 * MVX_PROFILE_RING events, created on first use
@@ -341,10 +341,10 @@ int run(mvx_handle *h, const RunArgs &r) {
     for (int b = 0; b < r.B; ++b) nmax = std::max<int64_t>(nmax, r.offsets[b + 1] - r.offsets[b]);
     const int64_t xstride = nmax + 2; // two header entries per list
     if ((rc = ensure(h->xlist, (size_t)r.B * nsx * (size_t)xstride * sizeof(uint2)))) return rc;
-    if ((rc = ensure(h->xcount, (size_t)r.B * nsx * nsy * nzc * 64 * sizeof(uint2)))) return rc; // slab lines
+    if ((rc = ensure(h->slist, (size_t)r.B * nsx * nsy * nzc * 64 * sizeof(uint2)))) return rc; // slab lines
     HIP_TRY(launch_xbin(pa.bbox, pa.xr, d_off, r.B, nsx, nsy, nzc, NW, (int32_t)xstride, reinterpret_cast<uint2 *>(h->xlist.p),
-                        reinterpret_cast<uint2 *>(h->xcount.p), s));
-    va.slist = reinterpret_cast<const uint2 *>(h->xcount.p);
+                        reinterpret_cast<uint2 *>(h->slist.p), s));
+    va.slist = reinterpret_cast<const uint2 *>(h->slist.p);
     va.p.xstride = (int32_t)xstride;
     va.xlist = reinterpret_cast<const uint2 *>(h->xlist.p);
     va.p.ncc = ncc;
@@ -447,7 +447,7 @@ int mvx_destroy(mvx_handle *h) {
     if (!h) return MVX_OK;
     DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&h->rec, &h->bbox, &h->xlist, &h->xcount, &h->meta, &h->aux, &h->in_coords, &h->in_chan, &h->in_radii, &h->out_stage};
+    DevBuf *bufs[] = {&h->rec, &h->bbox, &h->xlist, &h->slist, &h->meta, &h->aux, &h->in_coords, &h->in_chan, &h->in_radii, &h->out_stage};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (PinnedSlot &s : h->slots) {

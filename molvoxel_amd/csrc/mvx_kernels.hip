@@ -8,19 +8,19 @@
 // It is NOT a translation of that code (Python loop over 8^3 blocks, cdist -> (V,512) -> matmul) and
 // not of the torch path. Formulation: voxel-tile GATHER.
 //
-//   prep_kernel      one thread per atom: rigid transform in the reference's fp64 op order, exact
-//                    box cull + per-axis reference-block cull folded into an admitted voxel-index
-//                    range, exact membership threshold T on d2, gaussian coefficient k.
-//   voxelize_kernel  one workgroup per output slab of 4 x 4 x (4*NW) voxels (NW waves, one 4^3
-//                    sub-tile per wave, one voxel per lane, CT channel accumulators per lane in
-//                    registers). The workgroup scans the molecule's atom ranges for slab
-//                    candidates (ordered, ballot/prefix compaction), stages candidate records +
-//                    feature rows in LDS, every wave walks the candidates that touch its sub-tile
-//                    (fp64 d2, compare with T, exp2, packed FMAs), then the accumulators are
-//                    transposed through LDS and written with 16-B/lane stores in runs of full W
-//                    rows. Every output byte is written exactly once, zeros included (the
-//                    reference's overwrite semantics, numpy/voxelizer.py:133-135,158-160); no
-//                    atomics, no memset, no (V, DHW) intermediate, no MFMA (scatter-reduce).
+//   prep_kernel      one thread per atom: rigid transform in the reference's fp64 op order, exact box cull +
+//                    per-axis reference-block cull folded into an admitted voxel-index range, exact membership
+//                    threshold T on d2, gaussian coefficient k -> one row per atom [record | channel weights].
+//   xbin_kernel      ordered (ballot/prefix, no atomics) candidate lists: per (molecule, x-slab) and, from
+//                    those, one 512-B candidate line per output slab.
+//   voxelize_kernel  one workgroup per output slab of 2 x 4 x (8*NW) voxels (NW waves, one 2x4x8 sub-tile per
+//                    wave, one voxel per lane, CT channel accumulators per lane in registers): load the slab's
+//                    candidate line, stage the candidates' rows in LDS, every wave walks the candidates that
+//                    touch its sub-tile (fp64 d2, compare with T, exp2, packed FMAs), then the accumulators are
+//                    transposed through LDS and written with non-temporal 16-B/lane stores in whole-row runs.
+//                    Every output byte is written exactly once, zeros included (the reference's overwrite
+//                    semantics, numpy/voxelizer.py:133-135,158-160); no atomics, no memset, no (V, DHW)
+//                    intermediate, no MFMA (scatter-reduce, HBM-write bound).
 //
 // Exactness: membership float32(float32(sqrt_f64(d2))/r32) <= 1 is equivalent to d2 <= T with
 //   y  = largest fp64 whose float32 rounding is <= r32,  T = round_down(y * nextup(y))
@@ -321,7 +321,7 @@ constexpr int SLOTS = 64;    // slab list: header + 63 candidates
 
 __global__ void __launch_bounds__(256)
     xbin_kernel(const uint4 *__restrict__ bbox, const unsigned *__restrict__ xr, const int64_t *__restrict__ offsets, int nsx, int nsy, int nzc, int NW,
-                int xstride, uint2 *__restrict__ xlist, uint2 *__restrict__ slist, int ablate) {
+                int xstride, uint2 *__restrict__ xlist, uint2 *__restrict__ slist) {
     __shared__ uint2 xs[XL_LDS];
     __shared__ int wcnt[2][16];
     const int b = blockIdx.x / nsx, sx = blockIdx.x % nsx;
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(256)
     const int x0 = SUBX * sx;
     uint2 *dst = xlist + (size_t)blockIdx.x * (size_t)xstride; // fixed stride: addressable from blockIdx alone
     int count = 0, phase = 0;
-    for (int64_t base = a0; base < ((ablate & 16) ? a0 : a1); base += 1024, ++phase) {
+    for (int64_t base = a0; base < a1; base += 1024, ++phase) {
         unsigned xv[4]; // admitted x ranges (SoA: 4 B per atom); y/z ranges are fetched for matches only
         bool m[4];
         unsigned long long mask[4];
@@ -370,7 +370,6 @@ __global__ void __launch_bounds__(256)
     if (tid == 1) dst[1] = make_uint2((unsigned)a0, EMPTY_ENTRY);
     __syncthreads();
 
-    if (ablate & 8) return;
     const int nslab = nsy * nzc;
     uint2 *sl_base = slist + (size_t)blockIdx.x * (size_t)nslab * SLOTS;
     for (int sl = wave; sl < nslab; sl += 4) {
@@ -402,9 +401,8 @@ __global__ void __launch_bounds__(256)
 hipError_t launch_xbin(const uint4 *bbox, const unsigned *xr, const int64_t *offsets, int32_t B, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
                        int32_t xstride, uint2 *xlist, uint2 *slist, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    static const int ablate = std::getenv("MVX_XBIN_ABLATE") ? std::atoi(std::getenv("MVX_XBIN_ABLATE")) : 0;
     hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(256), 0, s, bbox, xr, offsets, nsx, nsy, nzc, NW, xstride,
-                       xlist, slist, ablate);
+                       xlist, slist);
     return hipGetLastError();
 }
 
