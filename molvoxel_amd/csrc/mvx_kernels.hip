@@ -570,10 +570,30 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
             acc[0].x = fmaf(val, f[0], acc[0].x);
         } else {
             const float2v v2 = (float2v){val, val};
+            if constexpr (CT >= 16) {
+                // software pipeline over the weight row: two 16-B LDS reads in flight while the packed FMAs of the
+                // previous pair issue (left to itself hipcc serialises read -> wait -> 2 FMAs eight times)
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v *f4 = reinterpret_cast<const f4v *>(f);
+                f4v A = f4[0], B = f4[1];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = 0; c < CT / 2; ++c) {
-                const float2v f2 = *reinterpret_cast<const float2v *>(f + 2 * c);
-                acc[c] = __builtin_elementwise_fma(v2, f2, acc[c]);
+                for (int g = 0; g < CT / 4; g += 2) {
+                    acc[2 * g + 0] = __builtin_elementwise_fma(v2, (float2v){A.x, A.y}, acc[2 * g + 0]);
+                    acc[2 * g + 1] = __builtin_elementwise_fma(v2, (float2v){A.z, A.w}, acc[2 * g + 1]);
+                    if (g + 2 < CT / 4) A = f4[g + 2];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[2 * g + 2] = __builtin_elementwise_fma(v2, (float2v){B.x, B.y}, acc[2 * g + 2]);
+                    acc[2 * g + 3] = __builtin_elementwise_fma(v2, (float2v){B.z, B.w}, acc[2 * g + 3]);
+                    if (g + 3 < CT / 4) B = f4[g + 3];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CT / 2; ++c) {
+                    const float2v f2 = *reinterpret_cast<const float2v *>(f + 2 * c);
+                    acc[c] = __builtin_elementwise_fma(v2, f2, acc[c]);
+                }
             }
         }
     };
