@@ -337,15 +337,17 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.xcd_swap = (h->xcd_swap && ((long long)nzc * nsy * nsx) % 8 == 0) ? 1 : 0;
     va.p.NW = NW;
     // x-slab binning (ordered lists per (molecule, x-slab), fixed-stride regions)
-    int64_t nmax = 1;
-    for (int b = 0; b < r.B; ++b) nmax = std::max<int64_t>(nmax, r.offsets[b + 1] - r.offsets[b]);
-    const int64_t xstride = nmax + 2; // two header entries per list
-    if ((rc = ensure(h->xlist, (size_t)r.B * nsx * (size_t)xstride * sizeof(uint2)))) return rc;
-    if ((rc = ensure(h->slist, (size_t)r.B * nsx * nsy * nzc * 64 * sizeof(uint2)))) return rc; // slab lines
-    HIP_TRY(launch_xbin(pa.bbox, pa.xr, d_off, r.B, nsx, nsy, nzc, NW, (int32_t)xstride, reinterpret_cast<uint2 *>(h->xlist.p),
-                        reinterpret_cast<uint2 *>(h->slist.p), s));
-    va.slist = reinterpret_cast<const uint2 *>(h->slist.p);
-    va.p.xstride = (int32_t)xstride;
+    // x-lists: packed regions, (sum(N) + 2*B) * nsx entries; slab lines: SLAB_LINE_ENTRIES entries per slab
+    if ((rc = ensure(h->xlist, ((size_t)total + 2 * (size_t)r.B) * nsx * sizeof(uint2)))) return rc;
+    const size_t nslabs = (size_t)r.B * nsx * nsy * nzc;
+    if ((rc = ensure(h->slist, nslabs * (SLAB_LINE_ENTRIES + SLAB_EXT_ENTRIES) * sizeof(uint2)))) return rc;
+    uint2 *d_slist = reinterpret_cast<uint2 *>(h->slist.p);
+    uint2 *d_slist_ext = d_slist + nslabs * SLAB_LINE_ENTRIES; // extension lines live behind the primary lines
+    HIP_TRY(launch_xbin(pa.bbox, pa.xr, d_off, r.B, nsx, nsy, nzc, NW, reinterpret_cast<uint2 *>(h->xlist.p), d_slist,
+                        d_slist_ext, s));
+    va.slist = d_slist;
+    va.slist_ext = d_slist_ext;
+    va.offsets = d_off;
     va.xlist = reinterpret_cast<const uint2 *>(h->xlist.p);
     va.p.ncc = ncc;
     va.p.dcap = voxelize_dcap(ct, NW);

@@ -74,7 +74,6 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
     int32_t NW;            // waves per workgroup = 4^3 sub-tiles per slab
     int32_t row_words;     // words per atom row (16 + Cpad)
     int32_t dcap;          // candidate rows staged per round
-    int32_t xstride;       // entries per (molecule, x-slab) list region = largest molecule of the batch
     int32_t vec_store;     // D % 4 == 0 and out 16-B aligned
     int32_t store_kind;    // 0 plain, 1 nt, 2 sc1 (MVX_STORE)
     int32_t ablate;        // timing experiments only (MVX_ABLATE): 1 no walk, 2 every slab empty, 4 no stores
@@ -84,7 +83,9 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
 struct VoxArgs {
     const unsigned *rows;  // per-atom rows (record + channel weights)
     const uint2 *xlist;    // x-slab lists (xbin_kernel)
-    const uint2 *slist;    // per-slab candidate lines (xbin_kernel), 64 entries each
+    const uint2 *slist;    // per-slab candidate lines (xbin_kernel), SLOTS entries each
+    const uint2 *slist_ext; // their extensions (entries 64..255), EXT_SLOTS entries each
+    const int64_t *offsets; // device copy of the batch offsets (x-list path only)
     const double *Tc;      // channel-wise features: per-channel d2 thresholds
     const float *kc;       //                        per-channel gaussian coefficients
     float *out;            // (B, C, D, D, D)
@@ -96,7 +97,9 @@ hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float
                            double *Tc, float *kc, hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
 hipError_t launch_xbin(const uint4 *bbox, const unsigned *xr, const int64_t *offsets, int32_t B, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
-                       int32_t xstride, uint2 *xlist, uint2 *slist, hipStream_t s);
+                       uint2 *xlist, uint2 *slist, uint2 *slist_ext, hipStream_t s);
+constexpr int SLAB_LINE_ENTRIES = 64;  // = SLOTS in mvx_kernels.hip
+constexpr int SLAB_EXT_ENTRIES = 192;  // = EXT_SLOTS
 hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf_dev, double *out, hipStream_t s);
 // ct: channels per thread (1, 4, 8, 16, 32); lane_range: per-lane index-range check needed
 hipError_t launch_voxelize(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);

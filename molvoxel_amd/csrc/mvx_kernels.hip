@@ -310,25 +310,31 @@ hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf
 //     no atomics, so downstream float sums are reproducible). Entry = {atom index in molecule, packed ranges}:
 //     admitted y range in SUBY-voxel slabs (lo | hi << 8) and admitted z range in SUBZ-voxel sub-tiles
 //     (lo << 16 | hi << 24) — all the later slab / sub-tile filters need (D <= 1024). List (b, sx) lives at
-//     xlist[(b*nsx + sx) * xstride]; entry 0 = {count, EMPTY}, entry 1 = {first atom of the molecule, EMPTY}.
+//     xlist[(a0 + 2*b) * nsx + sx * (N_b + 2)] (a0 = first atom, N_b = atoms of molecule b: regions are packed,
+//     so ragged batches cost sum(N) entries per x-slab); entry 0 = {count, EMPTY}, entry 1 = {a0, EMPTY}.
 //  B. slab lists: for every slab (sy, zc) of this x-slab the x-list is compacted once more against the slab's
 //     y/z box: slist[slab * SLOTS] = {count, first atom}, then up to SLOTS-1 entries. The voxelize kernel reads
-//     one 512-B line per slab instead of scanning; a count above SLOTS-1 sends that slab to the x-list path.
+//     512 B of it per 63 candidates instead of scanning; a count above SLOTS-1 (LINE_OVERFLOW) sends that slab
+//     to the x-list path.
 constexpr uint32_t EMPTY_ENTRY = 0x00ff00ffu; // y lo = z lo = 255, hi = 0: matches no slab
 constexpr int XL_HEADER = 2;
-constexpr int XL_LDS = 2048; // x-list entries cached in LDS for pass B
-constexpr int SLOTS = 64;    // slab list: header + 63 candidates
+constexpr int XL_LDS = 2048; // x-list entries cached in LDS for pass B (16 KB); longer lists are re-read from L2
+constexpr int SLOTS = 64;      // primary slab line: header + 63 candidates = 512 B, one per slab, densely packed
+constexpr int EXT_SLOTS = 192; // extension line (entries 64..255) in a separate array: touched only by dense slabs
+constexpr int LINE_CAP = SLOTS + EXT_SLOTS - 1; // candidates a slab can hold before it takes the x-list path
+constexpr unsigned LINE_OVERFLOW = 0xffffffffu;
+static_assert(SLOTS == SLAB_LINE_ENTRIES && EXT_SLOTS == SLAB_EXT_ENTRIES, "slab line sizes are shared with the host side");
 
 __global__ void __launch_bounds__(256)
     xbin_kernel(const uint4 *__restrict__ bbox, const unsigned *__restrict__ xr, const int64_t *__restrict__ offsets, int nsx, int nsy, int nzc, int NW,
-                int xstride, uint2 *__restrict__ xlist, uint2 *__restrict__ slist) {
+                uint2 *__restrict__ xlist, uint2 *__restrict__ slist, uint2 *__restrict__ slist_ext) {
     __shared__ uint2 xs[XL_LDS];
     __shared__ int wcnt[2][16];
     const int b = blockIdx.x / nsx, sx = blockIdx.x % nsx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t a0 = offsets[b], a1 = offsets[b + 1];
     const int x0 = SUBX * sx;
-    uint2 *dst = xlist + (size_t)blockIdx.x * (size_t)xstride; // fixed stride: addressable from blockIdx alone
+    uint2 *dst = xlist + ((size_t)a0 + 2 * (size_t)b) * nsx + (size_t)sx * (size_t)(a1 - a0 + XL_HEADER);
     int count = 0, phase = 0;
     for (int64_t base = a0; base < a1; base += 1024, ++phase) {
         unsigned xv[4]; // admitted x ranges (SoA: 4 B per atom); y/z ranges are fetched for matches only
@@ -368,41 +374,51 @@ __global__ void __launch_bounds__(256)
     }
     if (tid == 0) dst[0] = make_uint2((unsigned)count, EMPTY_ENTRY);
     if (tid == 1) dst[1] = make_uint2((unsigned)a0, EMPTY_ENTRY);
+    __threadfence_block(); // the tail of a long x-list is read back by this block in pass B
     __syncthreads();
 
     const int nslab = nsy * nzc;
     uint2 *sl_base = slist + (size_t)blockIdx.x * (size_t)nslab * SLOTS;
+    uint2 *ext_base = slist_ext + (size_t)blockIdx.x * (size_t)nslab * EXT_SLOTS;
     for (int sl = wave; sl < nslab; sl += 4) {
         const int sy = sl / nzc, zc = sl - sy * nzc;
         const int zt_lo = zc * NW, zt_hi = zt_lo + NW - 1;
         uint2 *out = sl_base + (size_t)sl * SLOTS;
+        uint2 *ext = ext_base + (size_t)sl * EXT_SLOTS;
         int n = 0;
-        if (count <= XL_LDS) {
-            for (int i0 = 0; i0 < count; i0 += 64) {
-                const int i = i0 + lane;
-                const uint2 en = xs[i < count ? i : 0];
-                const unsigned pk = (i < count) ? en.y : EMPTY_ENTRY;
-                const bool mm = ((int)(pk & 0xff) <= sy) && ((int)((pk >> 8) & 0xff) >= sy) &&
-                                ((int)((pk >> 16) & 0xff) <= zt_hi) && ((int)(pk >> 24) >= zt_lo);
-                const unsigned long long mk = __ballot(mm);
-                if (mm) {
-                    const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                    if (pos < SLOTS - 1) out[1 + pos] = en;
+        for (int i0 = 0; i0 < count; i0 += 64) {
+            const int i = i0 + lane;
+            uint2 en = make_uint2(0u, EMPTY_ENTRY);
+            if (i < count) {
+                if (i < XL_LDS) {
+                    en = xs[i];
+                } else { // beyond the LDS copy: this block's own stores, read back from L2 (agent scope bypasses L1)
+                    en.x = __hip_atomic_load(&dst[XL_HEADER + i].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    en.y = __hip_atomic_load(&dst[XL_HEADER + i].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                n += __popcll(mk);
             }
-        } else {
-            n = SLOTS; // x-list too long for the LDS copy: every slab of this x-slab takes the x-list path
+            const unsigned pk = en.y;
+            const bool mm = ((int)(pk & 0xff) <= sy) && ((int)((pk >> 8) & 0xff) >= sy) &&
+                            ((int)((pk >> 16) & 0xff) <= zt_hi) && ((int)(pk >> 24) >= zt_lo);
+            const unsigned long long mk = __ballot(mm);
+            if (mm) {
+                const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                if (pos < SLOTS - 1) out[1 + pos] = en;
+                else if (pos < LINE_CAP) ext[pos - (SLOTS - 1)] = en;
+            }
+            n += __popcll(mk);
         }
-        if (lane == 0) out[0] = make_uint2((unsigned)n, (unsigned)a0);
+        // more candidates than the line and its extension hold: the slab takes the x-list path
+        const unsigned hdr = (n > LINE_CAP) ? LINE_OVERFLOW : (unsigned)n;
+        if (lane == 0) out[0] = make_uint2(hdr, (unsigned)a0);
     }
 }
 
 hipError_t launch_xbin(const uint4 *bbox, const unsigned *xr, const int64_t *offsets, int32_t B, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
-                       int32_t xstride, uint2 *xlist, uint2 *slist, hipStream_t s) {
+                       uint2 *xlist, uint2 *slist, uint2 *slist_ext, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(256), 0, s, bbox, xr, offsets, nsx, nsy, nzc, NW, xstride,
-                       xlist, slist);
+    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(256), 0, s, bbox, xr, offsets, nsx, nsy, nzc, NW, xlist,
+                       slist, slist_ext);
     return hipGetLastError();
 }
 
@@ -411,8 +427,8 @@ hipError_t launch_xbin(const uint4 *bbox, const unsigned *xr, const int64_t *off
 // ------------------------------------------------------------------------------------------------
 // One workgroup = one slab of SUBX x SUBY x (SUBZ*NW) voxels; one wave = one 64-voxel sub-tile; one lane = one
 // voxel with CT channel accumulators in registers. grid = (slab id, molecule * ncc + channel chunk).
-//   fast path (slab list holds <= min(SLOTS-1, 8*NW) candidates; the normal case):
-//     1. every wave loads the slab's 512-B candidate line (lane l = entry l; lane 0 = {count, first atom});
+//   fast path (the slab line holds all the slab's candidates, <= SLOTS-1; the normal case), per round of 64 entries:
+//     1. every wave loads 512 B of the slab's candidate line (lane l = entry l; entry 0 = {count, first atom});
 //     2. stage: wave w copies the rows of candidates w, w+NW, ... (64-B record + CT channel weights, one
 //        coalesced load each, all in flight at once) into LDS; one barrier;
 //     3. walk: each wave picks the candidates whose z range touches its sub-tile straight from the line it holds
@@ -466,8 +482,10 @@ size_t voxelize_lds_bytes(int32_t ct, int32_t NW) {
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     voxelize_kernel(const unsigned *__restrict__ rows, const uint2 *__restrict__ xlist,
-                    const uint2 *__restrict__ slist, const double *__restrict__ Tc, const float *__restrict__ kc,
-                    float *__restrict__ out, const VoxParams P) {
+                    const uint2 *__restrict__ slist, const uint2 *__restrict__ slist_ext,
+                    const int64_t *__restrict__ offsets,
+                    const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
+                    const VoxParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CR = CT < 16 ? CT : 16; // channels per write-out round
     constexpr int NROUND = CT / CR;
@@ -513,7 +531,8 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
         cc = (int)z - b * P.ncc;
     }
     // the slab's candidate line: {count, first atom}, then {atom index, packed ranges} per candidate
-    const uint2 E = slist[((size_t)b * (size_t)gridDim.x + t) * SLOTS + lane];
+    const uint2 *__restrict__ line = slist + ((size_t)b * (size_t)gridDim.x + t) * SLOTS;
+    uint2 E = line[lane]; // entries 0..63 of the line (entry 0 = header)
     const unsigned ty = (P.nzc == 1) ? t : __umulhi(t, P.nzc_inv); // t / nzc
     const int zc = (int)(t - ty * P.nzc);
     const int sx = (P.nsy == 1) ? (int)ty : (int)__umulhi(ty, P.nsy_inv); // ty / nsy
@@ -598,45 +617,60 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
         }
     };
 
-    const int n_line = MVX_ABLATE(2) ? 0 : __builtin_amdgcn_readlane((int)E.x, 0);
+    const unsigned n_hdr = MVX_ABLATE(2) ? 0u : (unsigned)__builtin_amdgcn_readlane((int)E.x, 0);
     const int64_t a0 = (int64_t)(unsigned)__builtin_amdgcn_readlane((int)E.y, 0);
-    const int fast_cap = (SLOTS - 1) < 8 * NW ? (SLOTS - 1) : 8 * NW;
-    bool any_candidate = n_line > 0;
-    if (n_line <= fast_cap) {
-        // ---- fast path -------------------------------------------------------------------------------
-        if (n_line > 0) {
+    bool any_candidate = n_hdr > 0;
+    if (n_hdr != LINE_OVERFLOW) {
+        // ---- fast path: rounds of up to 64 line entries (one round unless the slab has more than 63 candidates) ----
+        const int n_line = (int)n_hdr;            // candidates sit in entries 1..n_line
+        const int RW = 8 * NW < 64 ? 8 * NW : 64; // entries per round = rows staged per round
+        // one round: entries [e0, e0 + RW) are in the lanes of Er (lane l = entry e0 + l)
+        auto do_round = [&](const uint2 Er, int e0) {
             unsigned v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int j = wave + u * NW; // candidate staged by this wave (wave-uniform)
+                const int sl = wave + u * NW; // row slot staged by this wave (wave-uniform) <-> entry e0 + sl
                 v[u] = 0u;
-                if (j < n_line) {
-                    const int ai = __builtin_amdgcn_readlane((int)E.x, j + 1);
+                if (sl < RW && e0 + sl >= 1 && e0 + sl <= n_line) {
+                    const int ai = __builtin_amdgcn_readlane((int)Er.x, sl & 63);
                     if (stager) v[u] = rows[(size_t)(a0 + ai) * (size_t)P.row_words + lane_word];
                 }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int j = wave + u * NW;
-                if (j < n_line && stager) un[j * SW + lane] = v[u];
+                const int sl = wave + u * NW;
+                if (sl < RW && e0 + sl >= 1 && e0 + sl <= n_line && stager) un[sl * SW + lane] = v[u];
             }
             __syncthreads();
             MVX_STAMP(3)
             if (!MVX_ABLATE(1)) {
-                const unsigned pk = E.y;
-                const bool ok = (lane >= 1) && (lane <= n_line) && ((int)((pk >> 16) & 0xff) <= zt_w) && ((int)(pk >> 24) >= zt_w);
+                const unsigned pk = Er.y;
+                const bool ok = (lane < RW) && (e0 + lane >= 1) && (e0 + lane <= n_line) && ((int)((pk >> 16) & 0xff) <= zt_w) &&
+                                ((int)(pk >> 24) >= zt_w);
                 unsigned long long mask = __ballot(ok);
                 while (mask) {
-                    const int jj = __builtin_ctzll(mask) - 1;
+                    const int sl = __builtin_ctzll(mask);
                     mask &= mask - 1;
-                    accumulate(un + jj * SW);
+                    accumulate(un + sl * SW);
                 }
             }
             MVX_STAMP(4)
+        };
+        if (n_line > 0) do_round(E, 0);
+        if (n_line >= RW) { // dense slab: the rest of the primary line and the extension line, RW entries at a time
+            const uint2 *__restrict__ ext = slist_ext + ((size_t)b * (size_t)gridDim.x + t) * EXT_SLOTS;
+            for (int e0 = RW; e0 <= n_line; e0 += RW) {
+                __syncthreads(); // rows of the previous round consumed
+                const int e = e0 + lane;
+                uint2 Er = make_uint2(0u, EMPTY_ENTRY);
+                if (lane < RW && e <= n_line) Er = (e < SLOTS) ? line[e] : ext[e - SLOTS];
+                do_round(Er, e0);
+            }
         }
     } else {
         // ---- x-list path: more candidates than the slab line holds ---------------------------------------
-        const uint2 *__restrict__ xl = xlist + ((size_t)b * P.nsx + sx) * (size_t)P.xstride;
+        const int64_t nmol = offsets[b + 1] - offsets[b];
+        const uint2 *__restrict__ xl = xlist + ((size_t)a0 + 2 * (size_t)b) * P.nsx + (size_t)sx * (size_t)(nmol + XL_HEADER);
         const int nx = (int)xl[0].x + XL_HEADER;
         for (int base = 0; base < nx; base += LCAP) {
             if (base > 0) __syncthreads(); // list / candidate rows of the previous round consumed
@@ -811,7 +845,7 @@ struct LaunchFn {
         }
         hipLaunchKernelGGL((voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>),
                            dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(p.B * p.ncc)), dim3(p.NW * 64), lds, s, a.rows,
-                           a.xlist, a.slist, a.Tc, a.kc, a.out, a.p);
+                           a.xlist, a.slist, a.slist_ext, a.offsets, a.Tc, a.kc, a.out, a.p);
         return hipGetLastError();
     }
 };

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "csrc")
-LIB_PATH = os.path.join(CSRC, "libmvx_hip.so")
+LIB_PATH = os.environ.get("MVX_LIB", os.path.join(CSRC, "libmvx_hip.so"))  # MVX_LIB: A/B experiments only
 
 MVX_HOST, MVX_DEVICE = 0, 1
 MVX_GAUSSIAN, MVX_BINARY = 0, 1

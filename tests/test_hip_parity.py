@@ -289,6 +289,59 @@ def test_dense_cluster_exceeds_candidate_capacity(mv):
     assert np.abs(outg - refg).max() <= 2e-4 * max(1.0, float(refg.max()) / 100)  # sums of ~1000 terms
 
 
+def test_medium_density_multi_round_slab_lines(mv):
+    """64 < candidates per slab <= 255: the slab line is consumed in several rounds of 64 entries."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(11)
+    D = 32
+    W_ = 0.5 * (D - 1)
+    xyz = rng.uniform(-W_ / 2, W_ / 2, (2000, 3))
+    t = rng.integers(0, 5, 2000)
+    v = mv.create_voxelizer(0.5, D, "scalar", "binary", "hip", output="numpy")
+    out = v.forward(xyz, None, t, 1.5)
+    assert np.array_equal(out, c_oracle.voxelize(xyz, t, 1.5, dimension=D, density="binary", num_channels=5))
+    f = rng.random((2000, 32)).astype(np.float32)
+    vg = mv.create_voxelizer(0.5, D, "scalar", "gaussian", "hip", output="numpy")
+    outg = vg.forward(xyz, None, f, 1.5)
+    refg = c_oracle.voxelize(xyz, f, 1.5, dimension=D)
+    assert np.array_equal(outg != 0, refg != 0)
+    assert np.abs(outg - refg).max() <= 2e-5  # sums of up to ~60 terms
+
+
+def test_long_x_list_beyond_lds_copy(mv):
+    """An x-slab list longer than the binning pass's LDS copy (2048 entries): its tail is re-read from L2."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(13)
+    D = 64
+    W_ = 0.5 * (D - 1)
+    xyz = rng.uniform(-W_ / 2, W_ / 2, (9000, 3))
+    xyz[:, 0] = rng.uniform(-0.4, 0.4, 9000)  # a plate: every atom in the same two or three x-slabs
+    t = rng.integers(0, 4, 9000)
+    v = mv.create_voxelizer(0.5, D, "scalar", "binary", "hip", output="numpy")
+    out = v.forward(xyz, None, t, 1.0)
+    assert np.array_equal(out, c_oracle.voxelize(xyz, t, 1.0, dimension=D, density="binary", num_channels=4))
+
+
+def test_ragged_batch_with_one_large_molecule(mv):
+    """Packed x-list regions: a 5000-atom molecule next to tiny ones in one launch."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(12)
+    D = 24
+    W_ = 0.5 * (D - 1)
+    sizes = [3, 5000, 0, 17, 1]
+    coords = [rng.uniform(-W_ / 2 - 1, W_ / 2 + 1, (n, 3)) for n in sizes]
+    types = [rng.integers(0, 3, n) for n in sizes]
+    offsets = np.cumsum([0] + sizes)
+    v = mv.create_voxelizer(0.5, D, "scalar", "binary", "hip", output="numpy")
+    out = v.forward_batch(np.concatenate(coords), offsets, None, np.concatenate(types), 1.0, num_channels=3)
+    for b, n in enumerate(sizes):
+        ref = c_oracle.voxelize(coords[b], types[b], 1.0, dimension=D, density="binary", num_channels=3) if n else 0
+        assert np.array_equal(out[b], ref + np.zeros_like(out[b])), b
+
+
 def test_transform_objects_on_device(mv):
     """T / RandomTransform on torch CUDA tensors equal the seeded reference results (goldens)."""
     import torch
