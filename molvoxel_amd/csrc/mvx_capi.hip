@@ -57,7 +57,7 @@ struct mvx_handle {
     Geom g;
     float sigma32;
     int device;
-    DevBuf rec, bbox, xlist, slist, meta, aux, in_coords, in_chan, in_radii, out_stage;
+    DevBuf rec, bbox, xlist, slist, overflow, meta, aux, in_coords, in_chan, in_radii, out_stage;
     PinnedSlot slots[NSLOTS];
     int next_slot = 0;
     std::vector<hipEvent_t> ev; // 2 * MVX_PROFILE_RING events, created on first use
@@ -347,6 +347,10 @@ int run(mvx_handle *h, const RunArgs &r) {
                         d_slist_ext, s));
     va.slist = d_slist;
     va.slist_ext = d_slist_ext;
+    if (nslabs * (size_t)ncc + 1 > (size_t)0x7fffffff) return fail(MVX_ERR_INVALID, "batch too large for one call");
+    if ((rc = ensure(h->overflow, (nslabs * (size_t)ncc + 1) * sizeof(int)))) return rc;
+    HIP_TRY(hipMemsetAsync(h->overflow.p, 0, sizeof(int), s));
+    va.overflow = reinterpret_cast<int *>(h->overflow.p);
     va.offsets = d_off;
     va.xlist = reinterpret_cast<const uint2 *>(h->xlist.p);
     va.p.ncc = ncc;
@@ -449,7 +453,7 @@ int mvx_destroy(mvx_handle *h) {
     if (!h) return MVX_OK;
     DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&h->rec, &h->bbox, &h->xlist, &h->slist, &h->meta, &h->aux, &h->in_coords, &h->in_chan, &h->in_radii, &h->out_stage};
+    DevBuf *bufs[] = {&h->rec, &h->bbox, &h->xlist, &h->slist, &h->overflow, &h->meta, &h->aux, &h->in_coords, &h->in_chan, &h->in_radii, &h->out_stage};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (PinnedSlot &s : h->slots) {

@@ -89,6 +89,7 @@ struct VoxArgs {
     const double *Tc;      // channel-wise features: per-channel d2 thresholds
     const float *kc;       //                        per-channel gaussian coefficients
     float *out;            // (B, C, D, D, D)
+    int *overflow;         // [0] = count (zeroed per call), [1..] ids of the slabs left to voxelize_dense_kernel
     VoxParams p;
 };
 

@@ -425,22 +425,27 @@ hipError_t launch_xbin(const uint4 *bbox, const unsigned *xr, const int64_t *off
 // ------------------------------------------------------------------------------------------------
 // voxelize
 // ------------------------------------------------------------------------------------------------
-// One workgroup = one slab of SUBX x SUBY x (SUBZ*NW) voxels; one wave = one 64-voxel sub-tile; one lane = one
-// voxel with CT channel accumulators in registers. grid = (slab id, molecule * ncc + channel chunk).
-//   fast path (the slab line holds all the slab's candidates, <= SLOTS-1; the normal case), per round of 64 entries:
-//     1. every wave loads 512 B of the slab's candidate line (lane l = entry l; entry 0 = {count, first atom});
-//     2. stage: wave w copies the rows of candidates w, w+NW, ... (64-B record + CT channel weights, one
-//        coalesced load each, all in flight at once) into LDS; one barrier;
-//     3. walk: each wave picks the candidates whose z range touches its sub-tile straight from the line it holds
-//        in registers (ballot) and processes them: broadcast LDS reads, fp64 d2 in cdist order, compare with T,
-//        exp2, packed FMAs;
-//   x-list path (more candidates than the line holds; dense clusters): wave 0 compacts the (molecule, x-slab)
-//        list in rounds of LCAP entries into an LDS list, rows are staged in rounds of dcap, same walk;
-//   4. write-out: accumulators -> LDS tile (CR = min(CT,16) channels per round) -> non-temporal 16-B/lane
-//      stores in whole-line runs. Empty slabs skip the LDS round trip.
-// LDS map (dynamic, 16-B aligned), LCAP = 64 * min(NW, 4):
-//   [0, 4*LCAP) int list[] | [4*LCAP, 8*LCAP) uint32 zr[] | [8*LCAP, +16) int nlist[] (x-list path only) |
-//   union { dcap x SW words of candidate rows ; (CR*RPC rows) x RS floats out tile }
+// Shared decomposition: one slab = SUBX x SUBY x (SUBZ*NW) voxels = NW waves, one 64-voxel sub-tile per wave, one
+// voxel per lane, CT channel accumulators per lane in registers. Every output byte is written exactly once (zeros
+// included) with 16-B/lane non-temporal stores in whole-row runs; no atomics, no memset, no MFMA.
+//
+// voxelize_kernel (the normal case: the slab's primary line holds all its candidates, <= 63).
+//   grid = (slab id, molecule * ncc + channel chunk), one workgroup per slab:
+//     1. every wave loads the slab's 512-B candidate line (lane l = entry l; entry 0 = {count, first atom});
+//     2. stage: wave w copies the rows of candidates w, w+NW, ... (64-B record + CT channel weights, one coalesced
+//        load each, indices by v_readlane, all loads in flight at once) into LDS; one barrier;
+//     3. walk: each wave picks the candidates whose z range touches its sub-tile straight from the line it holds in
+//        registers (ballot) and processes them: broadcast LDS reads, fp64 d2 in cdist order, compare with T, exp2,
+//        software-pipelined weight reads + packed FMAs;
+//     4. write-out: accumulators -> LDS tile (CR = min(CT,16) channels per round) -> stores. Empty slabs skip the
+//        LDS round trip.
+//   A slab with more candidates only appends its id to the overflow list and leaves.
+// voxelize_dense_kernel (dense clusters; usually the list is empty and the launch returns at once): a fixed grid
+//   loops over the overflow list. Per slab: rounds of 64 entries over the primary + extension line (<= 255
+//   candidates), or, beyond that, wave 0 compacts the (molecule, x-slab) list in rounds of LCAP entries into an
+//   LDS list and the rows are staged in rounds of dcap; same walk and write-out.
+// LDS map (dynamic, 16-B aligned): voxelize_kernel: union { 64 x SW words of rows ; (CR*RPC rows) x RS floats tile };
+//   dense kernel: int list[LCAP] | uint32 zr[LCAP] | int nlist | union { dcap rows ; tile }, LCAP = 64 * min(NW, 4).
 
 // 16-B output store. kind 0: plain (line stays in the XCD's L2); 1: nt; 2: sc1 (write-through). Output bytes are
 // written once and never re-read here; nt keeps them from displacing the re-read inputs (0.69 -> 0.54 ms, cfg-2).
@@ -460,18 +465,25 @@ __device__ __forceinline__ void store_f4(float *dst, const float4 v, int kind) {
 __host__ __device__ __forceinline__ int row_stride_floats(int NW) { return SUBZ * NW + 8; }
 __host__ __device__ __forceinline__ int cand_stride_words(int ct) { return 16 + (ct < 4 ? 4 : ct); }
 
-// candidate rows staged per round: what fits in the out tile's bytes, at least 64, at most the list capacity
+size_t voxelize_lds_bytes(int32_t ct, int32_t NW) {
+    const int cr = ct < 16 ? ct : 16;
+    const size_t tile = (size_t)cr * RPC * row_stride_floats(NW) * 4;
+    const size_t cand = (size_t)64 * cand_stride_words(ct) * 4;
+    return tile > cand ? tile : cand;
+}
+
+// dense kernel: candidate rows staged per round = what fits in the out tile's bytes, at least 64, at most LCAP
 int32_t voxelize_dcap(int32_t ct, int32_t NW) {
     const int cr = ct < 16 ? ct : 16;
     const int lcap = 64 * (NW < 4 ? NW : 4);
     const size_t tile = (size_t)cr * RPC * row_stride_floats(NW) * 4;
     int cap = (int)(tile / ((size_t)cand_stride_words(ct) * 4));
     if (cap < 64) cap = 64;
-    if (cap > lcap) cap = lcap;
+    if (cap > lcap && lcap >= 64) cap = lcap;
     return cap;
 }
 
-size_t voxelize_lds_bytes(int32_t ct, int32_t NW) {
+size_t dense_lds_bytes(int32_t ct, int32_t NW) {
     const int cr = ct < 16 ? ct : 16;
     const int lcap = 64 * (NW < 4 ? NW : 4);
     const size_t tile = (size_t)cr * RPC * row_stride_floats(NW) * 4;
@@ -479,246 +491,87 @@ size_t voxelize_lds_bytes(int32_t ct, int32_t NW) {
     return (size_t)8 * lcap + 16 + (tile > cand ? tile : cand);
 }
 
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
-__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
-    voxelize_kernel(const unsigned *__restrict__ rows, const uint2 *__restrict__ xlist,
-                    const uint2 *__restrict__ slist, const uint2 *__restrict__ slist_ext,
-                    const int64_t *__restrict__ offsets,
-                    const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
-                    const VoxParams P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// what a lane knows about its voxel and its workgroup's slab
+struct LaneCtx {
+    double gx, gy, gz; // voxel centre: axis[i] = i*res - width/2 (numpy/voxelizer.py:41-43)
+    int ix, iy, iz;
+    int zt_w;          // this wave's sub-tile index along z
+    int cbase;         // first channel of this workgroup's chunk
+};
+
+// One candidate (row r staged in LDS) into the accumulators.
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+__device__ __forceinline__ void accumulate_row(float2v (&acc)[(CT + 1) / 2], const unsigned *r, const LaneCtx &L, int C,
+                                               const double *__restrict__ Tc, const float *__restrict__ kc) {
+    const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
+    const double2 PzT = *reinterpret_cast<const double2 *>(r + 4); // pz, T
+    const uint4 q = *reinterpret_cast<const uint4 *>(r + 8);       // k, type, xr, yr
+    const double dx = Pxy.x - L.gx, dy = Pxy.y - L.gy, dz = PzT.x - L.gz;
+    const double d2 = (dx * dx + dy * dy) + dz * dz; // cdist order, no fma
+    bool hit = d2 <= PzT.y;
+    if (LANE_RANGE) {
+        const unsigned zr = r[12];
+        hit = hit && (L.ix >= (int)(q.z & 0xffff)) && (L.ix <= (int)(q.z >> 16)) && (L.iy >= (int)(q.w & 0xffff)) &&
+              (L.iy <= (int)(q.w >> 16)) && (L.iz >= (int)(zr & 0xffff)) && (L.iz <= (int)(zr >> 16));
+    }
+    const float d2f = (float)d2;
+    const float *f = reinterpret_cast<const float *>(r + 16);
+    float val = 0.0f;
+    if (!CHANWISE) {
+        // no early-out on "no lane hit": ~85 % of the filtered candidates hit, and a straight-line body pipelines
+        const float ev = GAUSS ? __builtin_amdgcn_exp2f(__uint_as_float(q.x) * d2f) : 1.0f;
+        val = hit ? ev : 0.0f;
+    }
+    if constexpr (CHANWISE) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int ch = (L.cbase + c < C) ? L.cbase + c : C - 1;
+            const float ev = GAUSS ? __builtin_amdgcn_exp2f(kc[ch] * d2f) : 1.0f;
+            const float vc = (hit && d2 <= Tc[ch]) ? ev : 0.0f;
+            if (c & 1) acc[c / 2].y = fmaf(vc, f[c], acc[c / 2].y);
+            else acc[c / 2].x = fmaf(vc, f[c], acc[c / 2].x);
+        }
+    } else if constexpr (CT == 1) {
+        acc[0].x = fmaf(val, f[0], acc[0].x);
+    } else {
+        const float2v v2 = (float2v){val, val};
+        if constexpr (CT >= 16) {
+            // software pipeline over the weight row: two 16-B LDS reads in flight while the packed FMAs of the
+            // previous pair issue (left to itself hipcc serialises read -> wait -> 2 FMAs eight times)
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v *f4 = reinterpret_cast<const f4v *>(f);
+            f4v A = f4[0], B = f4[1];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < CT / 4; g += 2) {
+                acc[2 * g + 0] = __builtin_elementwise_fma(v2, (float2v){A.x, A.y}, acc[2 * g + 0]);
+                acc[2 * g + 1] = __builtin_elementwise_fma(v2, (float2v){A.z, A.w}, acc[2 * g + 1]);
+                if (g + 2 < CT / 4) A = f4[g + 2];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[2 * g + 2] = __builtin_elementwise_fma(v2, (float2v){B.x, B.y}, acc[2 * g + 2]);
+                acc[2 * g + 3] = __builtin_elementwise_fma(v2, (float2v){B.z, B.w}, acc[2 * g + 3]);
+                if (g + 3 < CT / 4) B = f4[g + 3];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CT / 2; ++c) {
+                const float2v f2 = *reinterpret_cast<const float2v *>(f + 2 * c);
+                acc[c] = __builtin_elementwise_fma(v2, f2, acc[c]);
+            }
+        }
+    }
+}
+
+// Write-out of one slab. `any` false: zero fill without the LDS round trip. Begins with a barrier (the union region
+// may still hold candidate rows) and ends without one.
+template <int CT>
+__device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], bool any, float *tile, int tid, int lane,
+                                           int wave, int NW, int b, int cbase, int x0, int y0, int z0, float *out,
+                                           const VoxParams &P) {
     constexpr int CR = CT < 16 ? CT : 16; // channels per write-out round
     constexpr int NROUND = CT / CR;
-    constexpr int SW = 16 + (CT < 4 ? 4 : CT); // LDS words per candidate row (multiple of 4)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef MVX_DIAG
-    // diagnostic builds only (MVX_STAMPS): phase time stamps of thread 0 into a buffer nothing else reads
-    const size_t blk = blockIdx.x + (size_t)gridDim.x * blockIdx.y;
-#define MVX_STAMP(k) \
-    if (P.stamps && tid == 0) P.stamps[blk * 8 + (k)] = __builtin_amdgcn_s_memtime();
-#define MVX_ABLATE(bit) (P.ablate & (bit))
-#else
-#define MVX_STAMP(k)
-#define MVX_ABLATE(bit) 0
-#endif
-    MVX_STAMP(0)
-    const int NW = P.NW;
-    const int SB = NW < 4 ? NW : 4; // x-list entries per lane and scan round (x-list path)
-    const int LCAP = 64 * SB;
     const int D = P.D;
-
-    int *list = reinterpret_cast<int *>(smem);
-    unsigned *zr_l = reinterpret_cast<unsigned *>(smem + 4 * LCAP);
-    int *nlist_s = reinterpret_cast<int *>(smem + 8 * LCAP);
-    unsigned *un = reinterpret_cast<unsigned *>(smem + 8 * LCAP + 16);
-    float *tile = reinterpret_cast<float *>(un);
-
-    // ---- block -> (molecule * ncc + channel chunk, slab) -------------------------------------------
-    // grid = (T, Z): t = zc + nzc * (sy + nsy * sx) slab id, z = molecule * ncc + chunk. (MVX_XCD_SWAP=1 swaps the
-    // low three bits of t and z so that XCD k works through whole molecules; measured slower, kept as a knob.)
-    unsigned t = blockIdx.x, z = blockIdx.y;
-    if (P.xcd_swap && z < (gridDim.y & ~7u)) {
-        const unsigned tl = t & 7u, zl = z & 7u;
-        t = (t & ~7u) | zl;
-        z = (z & ~7u) | tl;
-    }
-    int b = (int)z, cc = 0;
-    if (P.ncc > 1) {
-        b = (int)z / P.ncc;
-        cc = (int)z - b * P.ncc;
-    }
-    // the slab's candidate line: {count, first atom}, then {atom index, packed ranges} per candidate
-    const uint2 *__restrict__ line = slist + ((size_t)b * (size_t)gridDim.x + t) * SLOTS;
-    uint2 E = line[lane]; // entries 0..63 of the line (entry 0 = header)
-    const unsigned ty = (P.nzc == 1) ? t : __umulhi(t, P.nzc_inv); // t / nzc
-    const int zc = (int)(t - ty * P.nzc);
-    const int sx = (P.nsy == 1) ? (int)ty : (int)__umulhi(ty, P.nsy_inv); // ty / nsy
-    const int sy = (int)ty - sx * P.nsy;
-    const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
-    const int zt_lo = zc * NW, zt_hi = zt_lo + NW - 1; // sub-tile index range of the slab along z
-    MVX_STAMP(1)
-
-    // ---- this lane's voxel ---------------------------------------------------------------------
-    const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1), lx = lane >> (SUBZ_SH + SUBY_SH);
-    const int ix = x0 + lx, iy = y0 + ly, iz = z0 + SUBZ * wave + lz;
-    const double gx = (double)ix * P.res - P.half; // axis[i] = i*res - width/2, numpy/voxelizer.py:41-43
-    const double gy = (double)iy * P.res - P.half;
-    const double gz = (double)iz * P.res - P.half;
-    const int zt_w = zt_lo + wave; // this wave's sub-tile index along z
-    // row word this lane stages: 0-15 record, 16.. the CT channel weights of chunk cc
-    const int lane_word = lane < 16 ? lane : lane + cc * CT;
-    const bool stager = lane < 16 + CT;
-
-    float2v acc[(CT + 1) / 2];
-#pragma unroll
-    for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
-
-    // one candidate: row r staged in LDS
-    auto accumulate = [&](const unsigned *r) {
-        const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
-        const double2 PzT = *reinterpret_cast<const double2 *>(r + 4); // pz, T
-        const uint4 q = *reinterpret_cast<const uint4 *>(r + 8);       // k, type, xr, yr
-        const double dx = Pxy.x - gx, dy = Pxy.y - gy, dz = PzT.x - gz;
-        const double d2 = (dx * dx + dy * dy) + dz * dz; // cdist order, no fma
-        bool hit = d2 <= PzT.y;
-        if (LANE_RANGE) {
-            const unsigned zr = r[12];
-            hit = hit && (ix >= (int)(q.z & 0xffff)) && (ix <= (int)(q.z >> 16)) && (iy >= (int)(q.w & 0xffff)) &&
-                  (iy <= (int)(q.w >> 16)) && (iz >= (int)(zr & 0xffff)) && (iz <= (int)(zr >> 16));
-        }
-        const float d2f = (float)d2;
-        const float *f = reinterpret_cast<const float *>(r + 16);
-        float val = 0.0f;
-        if (!CHANWISE) {
-            const float ev = GAUSS ? __builtin_amdgcn_exp2f(__uint_as_float(q.x) * d2f) : 1.0f;
-            val = hit ? ev : 0.0f;
-        }
-        if constexpr (CHANWISE) {
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const int ch = (cc * CT + c < P.C) ? cc * CT + c : P.C - 1;
-                const float ev = GAUSS ? __builtin_amdgcn_exp2f(kc[ch] * d2f) : 1.0f;
-                const float vc = (hit && d2 <= Tc[ch]) ? ev : 0.0f;
-                if (c & 1) acc[c / 2].y = fmaf(vc, f[c], acc[c / 2].y);
-                else acc[c / 2].x = fmaf(vc, f[c], acc[c / 2].x);
-            }
-        } else if constexpr (CT == 1) {
-            acc[0].x = fmaf(val, f[0], acc[0].x);
-        } else {
-            const float2v v2 = (float2v){val, val};
-            if constexpr (CT >= 16) {
-                // software pipeline over the weight row: two 16-B LDS reads in flight while the packed FMAs of the
-                // previous pair issue (left to itself hipcc serialises read -> wait -> 2 FMAs eight times)
-                typedef float f4v __attribute__((ext_vector_type(4)));
-                const f4v *f4 = reinterpret_cast<const f4v *>(f);
-                f4v A = f4[0], B = f4[1];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < CT / 4; g += 2) {
-                    acc[2 * g + 0] = __builtin_elementwise_fma(v2, (float2v){A.x, A.y}, acc[2 * g + 0]);
-                    acc[2 * g + 1] = __builtin_elementwise_fma(v2, (float2v){A.z, A.w}, acc[2 * g + 1]);
-                    if (g + 2 < CT / 4) A = f4[g + 2];
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc[2 * g + 2] = __builtin_elementwise_fma(v2, (float2v){B.x, B.y}, acc[2 * g + 2]);
-                    acc[2 * g + 3] = __builtin_elementwise_fma(v2, (float2v){B.z, B.w}, acc[2 * g + 3]);
-                    if (g + 3 < CT / 4) B = f4[g + 3];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < CT / 2; ++c) {
-                    const float2v f2 = *reinterpret_cast<const float2v *>(f + 2 * c);
-                    acc[c] = __builtin_elementwise_fma(v2, f2, acc[c]);
-                }
-            }
-        }
-    };
-
-    const unsigned n_hdr = MVX_ABLATE(2) ? 0u : (unsigned)__builtin_amdgcn_readlane((int)E.x, 0);
-    const int64_t a0 = (int64_t)(unsigned)__builtin_amdgcn_readlane((int)E.y, 0);
-    bool any_candidate = n_hdr > 0;
-    if (n_hdr != LINE_OVERFLOW) {
-        // ---- fast path: rounds of up to 64 line entries (one round unless the slab has more than 63 candidates) ----
-        const int n_line = (int)n_hdr;            // candidates sit in entries 1..n_line
-        const int RW = 8 * NW < 64 ? 8 * NW : 64; // entries per round = rows staged per round
-        // one round: entries [e0, e0 + RW) are in the lanes of Er (lane l = entry e0 + l)
-        auto do_round = [&](const uint2 Er, int e0) {
-            unsigned v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int sl = wave + u * NW; // row slot staged by this wave (wave-uniform) <-> entry e0 + sl
-                v[u] = 0u;
-                if (sl < RW && e0 + sl >= 1 && e0 + sl <= n_line) {
-                    const int ai = __builtin_amdgcn_readlane((int)Er.x, sl & 63);
-                    if (stager) v[u] = rows[(size_t)(a0 + ai) * (size_t)P.row_words + lane_word];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int sl = wave + u * NW;
-                if (sl < RW && e0 + sl >= 1 && e0 + sl <= n_line && stager) un[sl * SW + lane] = v[u];
-            }
-            __syncthreads();
-            MVX_STAMP(3)
-            if (!MVX_ABLATE(1)) {
-                const unsigned pk = Er.y;
-                const bool ok = (lane < RW) && (e0 + lane >= 1) && (e0 + lane <= n_line) && ((int)((pk >> 16) & 0xff) <= zt_w) &&
-                                ((int)(pk >> 24) >= zt_w);
-                unsigned long long mask = __ballot(ok);
-                while (mask) {
-                    const int sl = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    accumulate(un + sl * SW);
-                }
-            }
-            MVX_STAMP(4)
-        };
-        if (n_line > 0) do_round(E, 0);
-        if (n_line >= RW) { // dense slab: the rest of the primary line and the extension line, RW entries at a time
-            const uint2 *__restrict__ ext = slist_ext + ((size_t)b * (size_t)gridDim.x + t) * EXT_SLOTS;
-            for (int e0 = RW; e0 <= n_line; e0 += RW) {
-                __syncthreads(); // rows of the previous round consumed
-                const int e = e0 + lane;
-                uint2 Er = make_uint2(0u, EMPTY_ENTRY);
-                if (lane < RW && e <= n_line) Er = (e < SLOTS) ? line[e] : ext[e - SLOTS];
-                do_round(Er, e0);
-            }
-        }
-    } else {
-        // ---- x-list path: more candidates than the slab line holds ---------------------------------------
-        const int64_t nmol = offsets[b + 1] - offsets[b];
-        const uint2 *__restrict__ xl = xlist + ((size_t)a0 + 2 * (size_t)b) * P.nsx + (size_t)sx * (size_t)(nmol + XL_HEADER);
-        const int nx = (int)xl[0].x + XL_HEADER;
-        for (int base = 0; base < nx; base += LCAP) {
-            if (base > 0) __syncthreads(); // list / candidate rows of the previous round consumed
-            if (wave == 0) { // ordered compaction of LCAP entries against the slab's y/z box
-                int n = 0;
-                for (int u = 0; u < SB; ++u) {
-                    const int i = base + u * 64 + lane;
-                    const uint2 en = (i < nx) ? xl[i] : make_uint2(0u, EMPTY_ENTRY);
-                    // (the two header entries carry EMPTY_ENTRY and never match)
-                    const bool m = ((int)(en.y & 0xff) <= sy) && ((int)((en.y >> 8) & 0xff) >= sy) &&
-                                   ((int)((en.y >> 16) & 0xff) <= zt_hi) && ((int)(en.y >> 24) >= zt_lo);
-                    const unsigned long long mask = __ballot(m);
-                    if (m) {
-                        const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        list[pos] = (int)en.x;
-                        zr_l[pos] = en.y;
-                    }
-                    n += __popcll(mask);
-                }
-                if (lane == 0) nlist_s[0] = n;
-            }
-            __syncthreads();
-            const int nl = nlist_s[0];
-            for (int c0 = 0; c0 < nl; c0 += P.dcap) {
-                const int n = (nl - c0) < P.dcap ? (nl - c0) : P.dcap; // rows staged this round
-                if (c0 > 0) __syncthreads();
-                for (int j = wave; j < n; j += NW)
-                    if (stager) un[j * SW + lane] = rows[(size_t)(a0 + list[c0 + j]) * (size_t)P.row_words + lane_word];
-                __syncthreads();
-                for (int jb = 0; jb < n; jb += 64) {
-                    const int j = jb + lane;
-                    bool ok = false;
-                    if (j < n) {
-                        const unsigned zr = zr_l[c0 + j];
-                        ok = ((int)((zr >> 16) & 0xff) <= zt_w) && ((int)(zr >> 24) >= zt_w);
-                    }
-                    unsigned long long mask = __ballot(ok);
-                    while (mask) {
-                        const int jj = jb + __builtin_ctzll(mask);
-                        mask &= mask - 1;
-                        accumulate(un + jj * SW);
-                    }
-                }
-            }
-        }
-    }
-
-    // ---- 4. write-out ----------------------------------------------------------------------------
     const int RS = row_stride_floats(NW);
     const size_t D2 = (size_t)D * D, D3 = D2 * D;
     const int F4 = (SUBZ / 4) * NW; // float4 slots per row
@@ -727,10 +580,8 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     const int zq = z0 + 4 * q;
     const int sxx = (rfirst >> SUBY_SH) & (SUBX - 1), syy = rfirst & (SUBY - 1), cfirst = rfirst / RPC;
     const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
-    const int cbase = cc * CT;
     float *dst0 = out + ((size_t)b * P.C + cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
-    if (!any_candidate) {
-        // empty slab: pure zero fill with the same addressing (no LDS round trip)
+    if (!any) {
         if (vox_ok) {
 #pragma unroll
             for (int p = 0; p < (CT + 3) / 4; ++p) {
@@ -746,9 +597,9 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
                 }
             }
         }
-        MVX_STAMP(7)
         return;
     }
+    const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1), lx = lane >> (SUBZ_SH + SUBY_SH);
     const int col = SUBZ * wave + lz;
     const int rxy = lx * SUBY + ly;
 #pragma unroll
@@ -761,7 +612,6 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
             tile[(c * RPC + rxy) * RS + col] = v;
         }
         __syncthreads();
-        if (rd == 0) { MVX_STAMP(5) }
         if (vox_ok) {
 #pragma unroll
             for (int p = 0; p < (CR + 3) / 4; ++p) {
@@ -769,9 +619,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
                 if (c < CR && cbase + rd * CR + c < P.C) {
                     const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 4 * RPC * p) * RS + 4 * q);
                     float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
-                    if (MVX_ABLATE(4)) {
-                        if (v.x == 123.456f) dst[0] = v.y; // timing experiment: no stores
-                    } else if (P.vec_store) {
+                    if (P.vec_store) {
                         store_f4(dst, v, P.store_kind);
                     } else {
                         const float e4[4] = {v.x, v.y, v.z, v.w};
@@ -782,9 +630,229 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
             }
         }
     }
-    MVX_STAMP(7)
-#undef MVX_STAMP
-#undef MVX_ABLATE
+}
+
+// slab id t = zc + nzc * (sy + nsy * sx)
+__device__ __forceinline__ void decode_slab(unsigned t, const VoxParams &P, int &sx, int &sy, int &zc) {
+    const unsigned ty = (P.nzc == 1) ? t : __umulhi(t, P.nzc_inv); // t / nzc
+    zc = (int)(t - ty * P.nzc);
+    sx = (P.nsy == 1) ? (int)ty : (int)__umulhi(ty, P.nsy_inv); // ty / nsy
+    sy = (int)ty - sx * P.nsy;
+}
+
+__device__ __forceinline__ LaneCtx make_lane_ctx(int lane, int wave, int x0, int y0, int z0, int zt_lo, int cbase,
+                                                  const VoxParams &P) {
+    const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1), lx = lane >> (SUBZ_SH + SUBY_SH);
+    LaneCtx L;
+    L.ix = x0 + lx;
+    L.iy = y0 + ly;
+    L.iz = z0 + SUBZ * wave + lz;
+    L.gx = (double)L.ix * P.res - P.half;
+    L.gy = (double)L.iy * P.res - P.half;
+    L.gz = (double)L.iz * P.res - P.half;
+    L.zt_w = zt_lo + wave;
+    L.cbase = cbase;
+    return L;
+}
+
+// One round of the line path: entries [e0, e0 + RW) of a slab line sit in the lanes of Er (lane l = entry e0 + l);
+// candidates are entries 1..n_line. Stages their rows (slot = lane index) and walks them. Ends without a barrier.
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+__device__ __forceinline__ void line_round(float2v (&acc)[(CT + 1) / 2], const uint2 Er, int e0, int n_line, int RW,
+                                           unsigned *un, const unsigned *__restrict__ rows, int64_t a0, int lane, int wave,
+                                           int NW, const LaneCtx &L, const VoxParams &P, const double *__restrict__ Tc,
+                                           const float *__restrict__ kc) {
+    constexpr int SW = 16 + (CT < 4 ? 4 : CT);
+    const int lane_word = lane < 16 ? lane : lane + L.cbase; // 0-15 record, 16.. the CT channel weights of the chunk
+    const bool stager = lane < 16 + CT;
+    unsigned v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int sl = wave + u * NW; // row slot staged by this wave (wave-uniform) <-> entry e0 + sl
+        v[u] = 0u;
+        if (sl < RW && e0 + sl >= 1 && e0 + sl <= n_line) {
+            const int ai = __builtin_amdgcn_readlane((int)Er.x, sl & 63);
+            if (stager) v[u] = rows[(size_t)(a0 + ai) * (size_t)P.row_words + lane_word];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int sl = wave + u * NW;
+        if (sl < RW && e0 + sl >= 1 && e0 + sl <= n_line && stager) un[sl * SW + lane] = v[u];
+    }
+    __syncthreads();
+    const unsigned pk = Er.y;
+    const bool ok = (lane < RW) && (e0 + lane >= 1) && (e0 + lane <= n_line) && ((int)((pk >> 16) & 0xff) <= L.zt_w) &&
+                    ((int)(pk >> 24) >= L.zt_w);
+    unsigned long long mask = __ballot(ok);
+    while (mask) {
+        const int sl = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        accumulate_row<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, un + sl * SW, L, P.C, Tc, kc);
+    }
+}
+
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
+__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
+    voxelize_kernel(const unsigned *__restrict__ rows, const uint2 *__restrict__ slist, const double *__restrict__ Tc,
+                    const float *__restrict__ kc, float *__restrict__ out, int *__restrict__ overflow, const VoxParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = P.NW;
+    unsigned *un = reinterpret_cast<unsigned *>(smem);
+
+    // grid = (T, Z): t = slab id, z = molecule * ncc + chunk. (MVX_XCD_SWAP=1 swaps the low three bits of t and z so
+    // that XCD k works through whole molecules; measured slower, kept as a knob.)
+    unsigned t = blockIdx.x, z = blockIdx.y;
+    if (P.xcd_swap && z < (gridDim.y & ~7u)) {
+        const unsigned tl = t & 7u, zl = z & 7u;
+        t = (t & ~7u) | zl;
+        z = (z & ~7u) | tl;
+    }
+    int b = (int)z, cc = 0;
+    if (P.ncc > 1) {
+        b = (int)z / P.ncc;
+        cc = (int)z - b * P.ncc;
+    }
+    // the slab's candidate line: {count, first atom}, then {atom index, packed ranges} per candidate
+    const uint2 E = slist[((size_t)b * (size_t)gridDim.x + t) * SLOTS + lane];
+    int sx, sy, zc;
+    decode_slab(t, P, sx, sy, zc);
+    const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
+    const LaneCtx L = make_lane_ctx(lane, wave, x0, y0, z0, zc * NW, cc * CT, P);
+
+    float2v acc[(CT + 1) / 2];
+#pragma unroll
+    for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
+
+    const unsigned n_hdr = (unsigned)__builtin_amdgcn_readlane((int)E.x, 0);
+    const int64_t a0 = (int64_t)(unsigned)__builtin_amdgcn_readlane((int)E.y, 0);
+    const int RW = 8 * NW < 64 ? 8 * NW : 64; // rows this kernel can stage
+    if (n_hdr >= (unsigned)RW) { // includes LINE_OVERFLOW: dense slab, left to voxelize_dense_kernel
+        if (tid == 0) {
+            const int pos = atomicAdd(overflow, 1);
+            overflow[1 + pos] = (int)(z * gridDim.x + t);
+        }
+        return;
+    }
+    if (n_hdr > 0)
+        line_round<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, E, 0, (int)n_hdr, RW, un, rows, a0, lane, wave, NW, L, P, Tc, kc);
+    write_slab<CT>(acc, n_hdr > 0, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, cc * CT, x0, y0, z0, out, P);
+}
+
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+__global__ void __launch_bounds__(1024)
+    voxelize_dense_kernel(const unsigned *__restrict__ rows, const uint2 *__restrict__ xlist,
+                          const uint2 *__restrict__ slist, const uint2 *__restrict__ slist_ext,
+                          const int64_t *__restrict__ offsets, const double *__restrict__ Tc,
+                          const float *__restrict__ kc, float *__restrict__ out, const int *__restrict__ overflow,
+                          const VoxParams P, unsigned T) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SW = 16 + (CT < 4 ? 4 : CT);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = P.NW;
+    const int SB = NW < 4 ? NW : 4; // x-list entries per lane and scan round
+    const int LCAP = 64 * SB;
+    int *list = reinterpret_cast<int *>(smem);
+    unsigned *zr_l = reinterpret_cast<unsigned *>(smem + 4 * LCAP);
+    int *nlist_s = reinterpret_cast<int *>(smem + 8 * LCAP);
+    unsigned *un = reinterpret_cast<unsigned *>(smem + 8 * LCAP + 16);
+    const int count = overflow[0];
+    const int RW = 8 * NW < 64 ? 8 * NW : 64;
+
+    for (int w = blockIdx.x; w < count; w += gridDim.x) {
+        const unsigned id = (unsigned)overflow[1 + w];
+        const unsigned z = id / T, t = id - z * T;
+        int b = (int)z, cc = 0;
+        if (P.ncc > 1) {
+            b = (int)z / P.ncc;
+            cc = (int)z - b * P.ncc;
+        }
+        int sx, sy, zc;
+        decode_slab(t, P, sx, sy, zc);
+        const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
+        const int zt_lo = zc * NW, zt_hi = zt_lo + NW - 1;
+        const LaneCtx L = make_lane_ctx(lane, wave, x0, y0, z0, zt_lo, cc * CT, P);
+        const uint2 *__restrict__ line = slist + ((size_t)b * T + t) * SLOTS;
+        const uint2 *__restrict__ ext = slist_ext + ((size_t)b * T + t) * EXT_SLOTS;
+        const uint2 hdr = line[0];
+        const int64_t a0 = (int64_t)hdr.y;
+        float2v acc[(CT + 1) / 2];
+#pragma unroll
+        for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
+        bool any = false;
+
+        if (hdr.x != LINE_OVERFLOW) {
+            // rounds of RW entries over the primary line and its extension
+            const int n_line = (int)hdr.x;
+            any = n_line > 0;
+            for (int e0 = 0; e0 <= n_line && n_line > 0; e0 += RW) {
+                if (e0 > 0) __syncthreads(); // rows of the previous round consumed
+                const int e = e0 + lane;
+                uint2 Er = make_uint2(0u, EMPTY_ENTRY);
+                if (lane < RW && e <= n_line) Er = (e < SLOTS) ? line[e] : ext[e - SLOTS];
+                line_round<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, Er, e0, n_line, RW, un, rows, a0, lane, wave, NW, L, P, Tc, kc);
+            }
+        } else {
+            // x-list path: more candidates than a line and its extension hold
+            const int64_t nmol = offsets[b + 1] - offsets[b];
+            const uint2 *__restrict__ xl = xlist + ((size_t)a0 + 2 * (size_t)b) * P.nsx + (size_t)sx * (size_t)(nmol + XL_HEADER);
+            const int nx = (int)xl[0].x + XL_HEADER;
+            const int lane_word = lane < 16 ? lane : lane + L.cbase;
+            const bool stager = lane < 16 + CT;
+            for (int base = 0; base < nx; base += LCAP) {
+                __syncthreads(); // list / candidate rows of the previous round consumed
+                if (wave == 0) { // ordered compaction of LCAP entries against the slab's y/z box
+                    int n = 0;
+                    for (int u = 0; u < SB; ++u) {
+                        const int i = base + u * 64 + lane;
+                        const uint2 en = (i < nx) ? xl[i] : make_uint2(0u, EMPTY_ENTRY);
+                        // (the two header entries carry EMPTY_ENTRY and never match)
+                        const bool m = ((int)(en.y & 0xff) <= sy) && ((int)((en.y >> 8) & 0xff) >= sy) &&
+                                       ((int)((en.y >> 16) & 0xff) <= zt_hi) && ((int)(en.y >> 24) >= zt_lo);
+                        const unsigned long long mask = __ballot(m);
+                        if (m) {
+                            const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                            list[pos] = (int)en.x;
+                            zr_l[pos] = en.y;
+                        }
+                        n += __popcll(mask);
+                    }
+                    if (lane == 0) nlist_s[0] = n;
+                }
+                __syncthreads();
+                const int nl = nlist_s[0];
+                any = any || nl > 0;
+                for (int c0 = 0; c0 < nl; c0 += P.dcap) {
+                    const int n = (nl - c0) < P.dcap ? (nl - c0) : P.dcap; // rows staged this round
+                    if (c0 > 0) __syncthreads();
+                    for (int j = wave; j < n; j += NW)
+                        if (stager) un[j * SW + lane] = rows[(size_t)(a0 + list[c0 + j]) * (size_t)P.row_words + lane_word];
+                    __syncthreads();
+                    for (int jb = 0; jb < n; jb += 64) {
+                        const int j = jb + lane;
+                        bool ok = false;
+                        if (j < n) {
+                            const unsigned zr = zr_l[c0 + j];
+                            ok = ((int)((zr >> 16) & 0xff) <= L.zt_w) && ((int)(zr >> 24) >= L.zt_w);
+                        }
+                        unsigned long long mask = __ballot(ok);
+                        while (mask) {
+                            const int jj = jb + __builtin_ctzll(mask);
+                            mask &= mask - 1;
+                            accumulate_row<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, un + jj * SW, L, P.C, Tc, kc);
+                        }
+                    }
+                }
+            }
+        }
+        write_slab<CT>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, cc * CT, x0, y0, z0, out, P);
+        __syncthreads(); // tile consumed before the next slab's rows land in the union region
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -823,6 +891,30 @@ static hipError_t for_kernel(const KernelKey &k, Fn &&fn) {
     return hipErrorInvalidValue;
 }
 
+template <typename K>
+static hipError_t raise_lds_limit(K kernel, size_t lds, size_t &raised) {
+    if (lds > 64 * 1024 && lds > raised) { // above the default dynamic-LDS limit: raise it once per instantiation
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised = lds;
+    }
+    return hipSuccess;
+}
+
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+static hipError_t launch_dense(const VoxArgs &a, hipStream_t s) {
+    static size_t raised = 0;
+    const VoxParams &p = a.p;
+    const size_t lds = dense_lds_bytes(CT, p.NW);
+    auto kern = &voxelize_dense_kernel<CT, GAUSS, CHANWISE, LANE_RANGE>;
+    hipError_t e = raise_lds_limit(kern, lds, raised);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(512), dim3(p.NW * 64), lds, s, a.rows, a.xlist, a.slist, a.slist_ext, a.offsets, a.Tc,
+                       a.kc, a.out, a.overflow, a.p, (unsigned)(p.nzc * p.nsy * p.nsx));
+    return hipGetLastError();
+}
+
 struct LaunchFn {
     const VoxArgs &a;
     hipStream_t s;
@@ -831,22 +923,16 @@ struct LaunchFn {
         const VoxParams &p = a.p;
         if (p.B <= 0) return hipSuccess;
         if ((long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
+        static size_t raised = 0;
         static const size_t lds_pad = std::getenv("MVX_LDS_PAD") ? (size_t)std::atoi(std::getenv("MVX_LDS_PAD")) : 0; // experiments
         const size_t lds = voxelize_lds_bytes(CT, p.NW) + lds_pad;
-        if (lds > 64 * 1024) { // above the default dynamic-LDS limit: raise it once per instantiation
-            static size_t raised = 0;
-            if (lds > raised) {
-                hipError_t e = hipFuncSetAttribute(
-                    reinterpret_cast<const void *>(&voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-                raised = lds;
-            }
-        }
-        hipLaunchKernelGGL((voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>),
-                           dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(p.B * p.ncc)), dim3(p.NW * 64), lds, s, a.rows,
-                           a.xlist, a.slist, a.slist_ext, a.offsets, a.Tc, a.kc, a.out, a.p);
-        return hipGetLastError();
+        auto kern = &voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>;
+        hipError_t e = raise_lds_limit(kern, lds, raised);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(p.B * p.ncc)), dim3(p.NW * 64), lds, s,
+                           a.rows, a.slist, a.Tc, a.kc, a.out, a.overflow, a.p);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        return launch_dense<CT, GAUSS, CHANWISE, LANE_RANGE>(a, s);
     }
 };
 
