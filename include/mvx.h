@@ -176,10 +176,6 @@ int mvx_stream_sync(mvx_handle *h, void *stream);
  * k float; type int32; x/y/z admitted voxel ranges as lo | hi << 16; 12 B pad) to host memory.
  * Synchronises the stream. Lets the tests check the prep stage (transform, culls, thresholds) alone. */
 int mvx_debug_read_records(mvx_handle *h, void *host_dst, int64_t n, void *stream);
-/* Diagnostic builds only (env MVX_STAMPS=1 at mvx_create): 8 s_memtime stamps per workgroup of the last
- * voxelize launch (phase boundaries of wave 0), copied to host after a device synchronisation. */
-int mvx_debug_read_stamps(mvx_handle *h, void *host_dst, int64_t max_blocks, int64_t *blocks);
-
 #ifdef __cplusplus
 }
 #endif

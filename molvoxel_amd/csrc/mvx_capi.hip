@@ -64,10 +64,7 @@ struct mvx_handle {
     int ev_count = 0;           // timed launches recorded since the last read
     bool profiling = false;
     int force_nw = 0;
-    int ablate = 0;
-    int want_stamps = 0;
     size_t stamp_blocks = 0;
-    DevBuf stamps;
     int row_bytes = 64;
     int max_ct = 32;
     int xcd_swap = 0; // measured slower on cfg-2 (0.61 vs 0.56 ms): kept as an experiment knob (MVX_XCD_SWAP=1)
@@ -356,15 +353,6 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.ncc = ncc;
     va.p.dcap = voxelize_dcap(ct, NW);
     va.p.vec_store = (D % 4 == 0) ? 1 : 0;
-    va.p.ablate = h->ablate;
-    va.p.stamps = nullptr;
-    if (h->want_stamps) {
-        const size_t nblk = (size_t)r.B * ncc * nsx * nsy * nzc;
-        if ((rc = ensure(h->stamps, nblk * 8 * sizeof(unsigned long long)))) return rc;
-        HIP_TRY(hipMemsetAsync(h->stamps.p, 0, nblk * 8 * sizeof(unsigned long long), s));
-        va.p.stamps = reinterpret_cast<unsigned long long *>(h->stamps.p);
-        h->stamp_blocks = nblk;
-    }
     va.p.store_kind = h->store_kind;
     // a sub-tile lies inside one reference block when its edges divide blockdim (or there is a single block):
     // the block cull is then wave-uniform and already folded into the candidate ranges.
@@ -431,8 +419,6 @@ int mvx_create(const mvx_config *cfg, mvx_handle **out) {
     h->device = cfg->device;
     make_geom(h);
     if (const char *env = std::getenv("MVX_NW")) h->force_nw = std::atoi(env);
-    if (const char *env = std::getenv("MVX_ABLATE")) h->ablate = std::atoi(env);
-    if (const char *env = std::getenv("MVX_STAMPS")) h->want_stamps = std::atoi(env);
     if (const char *env = std::getenv("MVX_STORE")) h->store_kind = std::atoi(env);
     if (const char *env = std::getenv("MVX_CT")) h->max_ct = std::max(1, std::min(32, std::atoi(env)));
     if (const char *env = std::getenv("MVX_XCD_SWAP")) h->xcd_swap = std::atoi(env);
@@ -599,16 +585,6 @@ int mvx_last_kernel_ms(mvx_handle *h, float *ms) {
     const int i = h->ev_count - 1;
     HIP_TRY(hipEventSynchronize(h->ev[2 * i + 1]));
     HIP_TRY(hipEventElapsedTime(ms, h->ev[2 * i], h->ev[2 * i + 1]));
-    return MVX_OK;
-}
-
-int mvx_debug_read_stamps(mvx_handle *h, void *host_dst, int64_t max_blocks, int64_t *blocks) {
-    if (!h || !host_dst || !blocks) return fail(MVX_ERR_INVALID, "bad argument");
-    DeviceGuard guard(h->device);
-    const size_t n = std::min<size_t>(h->stamp_blocks, (size_t)max_blocks);
-    HIP_TRY(hipDeviceSynchronize());
-    if (n) HIP_TRY(hipMemcpy(host_dst, h->stamps.p, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    *blocks = (int64_t)n;
     return MVX_OK;
 }
 

@@ -76,8 +76,6 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
     int32_t dcap;          // candidate rows staged per round
     int32_t vec_store;     // D % 4 == 0 and out 16-B aligned
     int32_t store_kind;    // 0 plain, 1 nt, 2 sc1 (MVX_STORE)
-    int32_t ablate;        // timing experiments only (MVX_ABLATE): 1 no walk, 2 every slab empty, 4 no stores
-    unsigned long long *stamps; // diagnostic builds only (MVX_STAMPS=1): 8 time stamps per workgroup, else null
 };
 
 struct VoxArgs {

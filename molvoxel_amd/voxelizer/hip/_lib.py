@@ -59,7 +59,6 @@ SIGNATURES = {
     "mvx_set_profiling": (C.c_int, [Handle, _i32]),
     "mvx_profile_read": (C.c_int, [Handle, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]),
     "mvx_last_kernel_ms": (C.c_int, [Handle, C.POINTER(C.c_float)]),
-    "mvx_debug_read_stamps": (C.c_int, [Handle, _vp, _i64, C.POINTER(_i64)]),
     "mvx_debug_read_records": (C.c_int, [Handle, _vp, _i64, _vp]),
     "mvx_alloc": (C.c_int, [Handle, _i64, C.POINTER(C.c_void_p)]),
     "mvx_free": (C.c_int, [Handle, _vp]),
