@@ -84,13 +84,13 @@ def cpu_baseline(budget_s: float):
     return port
 
 
-def load_pmc_traffic(batch: int):
+def load_pmc_traffic(molecules_per_launch: int):
     """HBM bytes per voxelize launch from the committed rocprofv3 --pmc summary, if it matches this config."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
-        if d.get("workload") == "cfg2" and int(d.get("batch", -1)) == batch:
+        if d.get("workload") == "cfg2" and int(d.get("molecules_per_launch", -1)) == molecules_per_launch:
             return float(d["hbm_bytes_per_launch"])
     except Exception:
         pass
@@ -164,7 +164,10 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        alg_bytes = B * wl.algorithmic_bytes(0)  # per launch: B molecules x (4*C*D^3 + N*(24 + 4*C + 4))
+        # the library cuts a step's batch into equal chunks of molecules (pre-pass of chunk k+1 overlaps the
+        # voxelize launch of chunk k): per launch = B / launches_per_step molecules x (4*C*D^3 + N*(24 + 4*C + 4))
+        lps = max(1, len(kernel_ms) // args.steps)
+        alg_bytes = (B // lps) * wl.algorithmic_bytes(0)
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         res = {
@@ -196,8 +199,10 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS,
                 "kernel_ms_avg": k_ms,
                 "kernel_launches_timed": len(kernel_ms),
+                "launches_per_step": lps,
+                "molecules_per_launch": B // lps,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "traffic": load_pmc_traffic(B),
+                "traffic": load_pmc_traffic(B // lps),
             },
         }
         if args.gpus == 1 and args.cpu_seconds > 0:

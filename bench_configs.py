@@ -50,7 +50,7 @@ def run(name, wl, batch_ids, steps, warmup=3):
         step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    k_ms = float(np.mean(vox.read_kernel_times_ms()))
+    k_ms = float(np.sum(vox.read_kernel_times_ms())) / steps  # voxelize launches of one call, summed
     alg = sum(wl.algorithmic_bytes(i) for i in batch_ids)
     return dict(config=name, batch=B, atoms=int(offsets[-1]), kernel_ms=k_ms, GBps=alg / (k_ms * 1e-3) / 1e9,
                 ms_per_call=1e3 * el / steps, molecules_per_s=B * steps / el)

@@ -16,7 +16,7 @@ constexpr int SUBX = 1 << SUBX_SH, SUBY = 1 << SUBY_SH, SUBZ = 1 << SUBZ_SH;
 static_assert(SUBX * SUBY * SUBZ == 64, "one voxel per lane");
 constexpr int RPC = SUBX * SUBY; // tile rows per channel
 
-// Per-atom record written by the prep kernel and consumed by the voxelize kernel (64 B, AoS so
+// Per-atom record written by the prep kernel and consumed by the voxelize kernels (64 B, AoS so
 // that one 16-lane dword load moves a whole record into LDS).
 struct __attribute__((aligned(16))) AtomRec {
     double px, py, pz; // coordinates after centring / transform (fp64, reference op order)
@@ -47,10 +47,11 @@ struct PrepArgs {
     const int32_t *types;   // (total,) or null
     const float *features;  // (total, C) or null
     int32_t mode;           // Mode: which channel weights go behind the records
-    int32_t Cpad;           // channel weights per row (zero padded)
+    int32_t Cpad;           // channel weights per atom in wbuf (zero padded)
     const int64_t *offsets; // device, B + 1
     const mvx_xform *xforms; // device, B records, or null
     const float *chan_aux;  // device: [0] = max channel radius (float32) for RAD_CHANNEL_FEATURES
+    int64_t first;          // atoms [first, total) are processed by this launch (pipelined chunks)
     int64_t total;
     int32_t B;
     int32_t C;
@@ -59,10 +60,10 @@ struct PrepArgs {
     int32_t density;
     float sigma32;
     Geom g;
-    char *rows;        // per-atom rows: [AtomRec 64 B | Cpad channel weights]
-    int32_t row_bytes; // 64 + 4 * Cpad
-    uint4 *bbox;       // {xr, yr, zr, 0} copy of the ranges for the binning pass
-    unsigned *xr;      // admitted x ranges alone (4 B per atom): what every x-slab block of the binning pass scans
+    AtomRec *rec;      // per-atom records
+    float *wbuf;       // packed channel weights (Cpad per atom: features zero padded / one-hot type / 1), or null when
+                       // the voxelize kernels read the caller's feature rows directly (features, C == Cpad)
+    uint2 *xp;         // what the binning pass scans, 8 B per atom: {admitted x range, packed y/z ranges in slab units}
 };
 
 struct VoxParams { // by-value kernel parameters (scalars only: pointers are separate __restrict__ arguments)
@@ -70,16 +71,17 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
     int32_t D, C, B;
     int32_t nsx, nsy, nzc, ncc; // slabs along x, along y, z chunks, channel chunks
     uint32_t nsy_inv, nzc_inv; // ceil(2^32 / d): n / d == __umulhi(n, inv) for the slab ids used here (n * d < 2^32)
-    int32_t xcd_swap;      // 1: swap the low 3 bits of slab id and molecule id (XCD-affine molecules; experiment knob MVX_XCD_SWAP=1, default off)
+    int32_t b0;            // first molecule of this launch (blockIdx.y = (molecule - b0) * ncc + channel chunk)
     int32_t NW;            // waves per workgroup = 4^3 sub-tiles per slab
-    int32_t row_words;     // words per atom row (16 + Cpad)
+    int32_t w_stride;      // floats between the channel weights of consecutive atoms
     int32_t dcap;          // candidate rows staged per round
     int32_t vec_store;     // D % 4 == 0 and out 16-B aligned
     int32_t store_kind;    // 0 plain, 1 nt, 2 sc1 (MVX_STORE)
 };
 
 struct VoxArgs {
-    const unsigned *rows;  // per-atom rows (record + channel weights)
+    const unsigned *rec;   // per-atom records (16 words each)
+    const unsigned *w;     // channel weights: the caller's feature rows or prep's packed copy (p.w_stride apart)
     const uint2 *xlist;    // x-slab lists (xbin_kernel)
     const uint2 *slist;    // per-slab candidate lines (xbin_kernel), SLOTS entries each
     const uint2 *slist_ext; // their extensions (entries 64..255), EXT_SLOTS entries each
@@ -95,13 +97,16 @@ struct VoxArgs {
 hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax,
                            double *Tc, float *kc, hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
-hipError_t launch_xbin(const uint4 *bbox, const unsigned *xr, const int64_t *offsets, int32_t B, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
-                       uint2 *xlist, uint2 *slist, uint2 *slist_ext, hipStream_t s);
+hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int32_t b0, int32_t nb, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
+                       uint2 *xlist, uint2 *slist, uint2 *slist_ext, int *zero_counter, hipStream_t s);
 constexpr int SLAB_LINE_ENTRIES = 64;  // = SLOTS in mvx_kernels.hip
 constexpr int SLAB_EXT_ENTRIES = 192;  // = EXT_SLOTS
 hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf_dev, double *out, hipStream_t s);
 // ct: channels per thread (1, 4, 8, 16, 32); lane_range: per-lane index-range check needed
-hipError_t launch_voxelize(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
+// voxelize molecules [a.p.b0, a.p.b0 + nb); slabs with more candidates than one line go to the overflow list
+hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
+// process the overflow list of all launches since it was zeroed (one launch per call)
+hipError_t launch_voxelize_dense(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
 hipError_t configure_kernels(); // raises the dynamic-LDS limit of every instantiation
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW);
 int32_t voxelize_dcap(int32_t ct, int32_t NW);

@@ -163,35 +163,25 @@ __device__ __forceinline__ void block_interval(const Geom &g, double p, double r
 
 // lo = 0xffff, hi = 0: fails every overlap test (lo <= box_hi needs box_hi >= 65535, beyond any grid)
 constexpr uint32_t EMPTY_RANGE = 0x0000ffffu;
+constexpr uint32_t EMPTY_ENTRY = 0x00ff00ffu; // packed y/z slab ranges: y lo = z lo = 255, hi = 0: matches no slab
 
-// Also writes the channel weights behind each record (features / one-hot type / 1, zero padded to Cpad): the
-// block copies the weights of its 256 atoms cooperatively, coalesced on the source side.
+// Packs the channel weights too when the voxelize kernels cannot read the caller's feature rows as they are
+// (one-hot type / 1 / zero padded features): the block copies the weights of its 256 atoms cooperatively.
 __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
-    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    {   // channel weights of atoms [blockIdx.x * 256, +256)
-        const int64_t first = (int64_t)blockIdx.x * 256;
+    const int64_t a = A.first + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (A.wbuf) {
+        const int64_t first = A.first + (int64_t)blockIdx.x * 256;
         const int nat = (int)((A.total - first) < 256 ? (A.total - first) : 256);
-        const int row_words = A.row_bytes / 4;
-        float *rows = reinterpret_cast<float *>(A.rows) + first * row_words + 16;
-        if (A.mode == MODE_FEATURES && A.C == A.Cpad && (A.Cpad & 3) == 0) {
-            // the block's weights are one contiguous run of nat * C floats: 16-B copies, 32-bit index math
-            const int q4 = A.Cpad >> 2;
-            const float4 *src = reinterpret_cast<const float4 *>(A.features + first * A.C);
-            for (int i = threadIdx.x; i < nat * q4; i += 256) {
-                const int al = i / q4, c4 = i - al * q4;
-                *reinterpret_cast<float4 *>(rows + (size_t)al * row_words + 4 * c4) = src[i];
+        float *wb = A.wbuf + first * A.Cpad;
+        for (int i = threadIdx.x; i < nat * A.Cpad; i += 256) {
+            const int al = i / A.Cpad, c = i - al * A.Cpad;
+            float f = 0.0f;
+            if (c < A.C) {
+                if (A.mode == MODE_FEATURES) f = A.features[(first + al) * A.C + c];
+                else if (A.mode == MODE_TYPES) f = (A.types[first + al] == c) ? 1.0f : 0.0f;
+                else f = 1.0f;
             }
-        } else {
-            for (int i = threadIdx.x; i < nat * A.Cpad; i += 256) {
-                const int al = i / A.Cpad, c = i - al * A.Cpad;
-                float f = 0.0f;
-                if (c < A.C) {
-                    if (A.mode == MODE_FEATURES) f = A.features[(first + al) * A.C + c];
-                    else if (A.mode == MODE_TYPES) f = (A.types[first + al] == c) ? 1.0f : 0.0f;
-                    else f = 1.0f;
-                }
-                rows[(size_t)al * row_words + c] = f;
-            }
+            wb[i] = f;
         }
     }
     if (a >= A.total) return;
@@ -273,14 +263,18 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
     R.xr = rng[0];
     R.yr = rng[1];
     R.zr = rng[2];
-    *reinterpret_cast<AtomRec *>(A.rows + (size_t)a * A.row_bytes) = R; // row = 64-B record + padded channel weights
-    A.bbox[a] = make_uint4(rng[0], rng[1], rng[2], 0u);
-    A.xr[a] = rng[0];
+    A.rec[a] = R;
+    // y range in SUBY-voxel slabs (lo | hi << 8), z range in SUBZ-voxel sub-tiles (lo << 16 | hi << 24); a dropped
+    // atom matches no slab (EMPTY_ENTRY)
+    const uint32_t packed = !keep ? EMPTY_ENTRY
+                                  : ((rng[1] & 0xffff) >> SUBY_SH) | (((rng[1] >> 16) >> SUBY_SH) << 8) |
+                                        (((rng[2] & 0xffff) >> SUBZ_SH) << 16) | (((rng[2] >> 16) >> SUBZ_SH) << 24);
+    A.xp[a] = make_uint2(rng[0], packed);
 }
 
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s) {
-    if (a.total <= 0) return hipSuccess;
-    const unsigned blocks = (unsigned)((a.total + 255) / 256);
+    if (a.total <= a.first) return hipSuccess;
+    const unsigned blocks = (unsigned)((a.total - a.first + 255) / 256);
     hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -316,9 +310,8 @@ hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf
 //     y/z box: slist[slab * SLOTS] = {count, first atom}, then up to SLOTS-1 entries. The voxelize kernel reads
 //     512 B of it per 63 candidates instead of scanning; a count above SLOTS-1 (LINE_OVERFLOW) sends that slab
 //     to the x-list path.
-constexpr uint32_t EMPTY_ENTRY = 0x00ff00ffu; // y lo = z lo = 255, hi = 0: matches no slab
 constexpr int XL_HEADER = 2;
-constexpr int XL_LDS = 2048; // x-list entries cached in LDS for pass B (16 KB); longer lists are re-read from L2
+constexpr int XL_LDS = 1024; // x-list entries cached in LDS for pass B (8 KB; + 8 KB of lines: 8 blocks per CU); longer lists are re-read from L2
 constexpr int SLOTS = 64;      // primary slab line: header + 63 candidates = 512 B, one per slab, densely packed
 constexpr int EXT_SLOTS = 192; // extension line (entries 64..255) in a separate array: touched only by dense slabs
 constexpr int LINE_CAP = SLOTS + EXT_SLOTS - 1; // candidates a slab can hold before it takes the x-list path
@@ -326,99 +319,146 @@ constexpr unsigned LINE_OVERFLOW = 0xffffffffu;
 static_assert(SLOTS == SLAB_LINE_ENTRIES && EXT_SLOTS == SLAB_EXT_ENTRIES, "slab line sizes are shared with the host side");
 
 __global__ void __launch_bounds__(256)
-    xbin_kernel(const uint4 *__restrict__ bbox, const unsigned *__restrict__ xr, const int64_t *__restrict__ offsets, int nsx, int nsy, int nzc, int NW,
-                uint2 *__restrict__ xlist, uint2 *__restrict__ slist, uint2 *__restrict__ slist_ext) {
+    xbin_kernel(const uint2 *__restrict__ xp, const int64_t *__restrict__ offsets, int b0, int nsx, int nsy, int nzc, int NW,
+                uint2 *__restrict__ xlist, uint2 *__restrict__ slist, uint2 *__restrict__ slist_ext, int *zero_counter) {
     __shared__ uint2 xs[XL_LDS];
     __shared__ int wcnt[2][16];
-    const int b = blockIdx.x / nsx, sx = blockIdx.x % nsx;
+    __shared__ int any_overflow;
+    __shared__ uint2 line[4][4 * SLOTS]; // the four slab lines each wave is building
+    const int b = b0 + blockIdx.x / nsx, sx = blockIdx.x % nsx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t a0 = offsets[b], a1 = offsets[b + 1];
     const int x0 = SUBX * sx;
+    if (zero_counter && blockIdx.x == 0 && tid == 0) *zero_counter = 0; // overflow list of the voxelize launches
+    if (tid == 0) any_overflow = 0;
     uint2 *dst = xlist + ((size_t)a0 + 2 * (size_t)b) * nsx + (size_t)sx * (size_t)(a1 - a0 + XL_HEADER);
     int count = 0, phase = 0;
-    for (int64_t base = a0; base < a1; base += 1024, ++phase) {
-        unsigned xv[4]; // admitted x ranges (SoA: 4 B per atom); y/z ranges are fetched for matches only
-        bool m[4];
-        unsigned long long mask[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { // four chunks of 256 atoms in flight
-            const int64_t a = base + u * 256 + tid;
-            xv[u] = (a < a1) ? xr[a] : 0x0000ffffu;
-        }
+    // four chunks of 256 atoms per round; the next round's loads are issued before this round's barrier. Loads past
+    // the molecule are clamped to its last atom and masked by value (a select between a global and a private
+    // address would turn them into flat loads).
+    if (a1 > a0) {
+        uint2 cur[4], nxt[4];
+        const int64_t alast = a1 - 1;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            m[u] = ((int)(xv[u] & 0xffff) <= x0 + SUBX - 1) && ((int)(xv[u] >> 16) >= x0);
-            mask[u] = __ballot(m[u]);
-            if (lane == 0) wcnt[phase & 1][u * 4 + wave] = __popcll(mask[u]);
+            const int64_t a = a0 + u * 256 + tid;
+            cur[u] = xp[a < a1 ? a : alast];
+            if (a >= a1) cur[u].x = EMPTY_RANGE;
         }
-        __syncthreads();
-        int run = count;
+        for (int64_t base = a0; base < a1; base += 1024, ++phase) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int c = wcnt[phase & 1][u * 4 + w];
-                if (w == wave && m[u]) {
-                    const int pos = run + __builtin_amdgcn_mbcnt_hi((unsigned)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[u], 0u));
-                    const uint4 bb = bbox[base + u * 256 + tid];
-                    const unsigned packed = ((bb.y & 0xffff) >> SUBY_SH) | (((bb.y >> 16) >> SUBY_SH) << 8) |
-                                            (((bb.z & 0xffff) >> SUBZ_SH) << 16) | (((bb.z >> 16) >> SUBZ_SH) << 24);
-                    const uint2 en = make_uint2((unsigned)(base + u * 256 + tid - a0), packed);
-                    dst[XL_HEADER + pos] = en;
-                    if (pos < XL_LDS) xs[pos] = en;
-                }
-                run += c;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t a = base + 1024 + u * 256 + tid;
+                nxt[u] = xp[a < a1 ? a : alast];
+                if (a >= a1) nxt[u].x = EMPTY_RANGE;
             }
+            bool m[4];
+            unsigned long long mask[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                m[u] = ((int)(cur[u].x & 0xffff) <= x0 + SUBX - 1) && ((int)(cur[u].x >> 16) >= x0);
+                mask[u] = __ballot(m[u]);
+                if (lane == 0) wcnt[phase & 1][u * 4 + wave] = __popcll(mask[u]);
+            }
+            __syncthreads();
+            int run = count;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int c = wcnt[phase & 1][u * 4 + w];
+                    if (w == wave && m[u]) {
+                        const int pos = run + __builtin_amdgcn_mbcnt_hi((unsigned)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[u], 0u));
+                        const uint2 en = make_uint2((unsigned)(base + u * 256 + tid - a0), cur[u].y);
+                        if (pos < XL_LDS) xs[pos] = en;
+                        else dst[XL_HEADER + pos] = en; // beyond the LDS copy: straight to the global list
+                    }
+                    run += c;
+                }
+            }
+            count = run;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
         }
-        count = run;
     }
-    if (tid == 0) dst[0] = make_uint2((unsigned)count, EMPTY_ENTRY);
-    if (tid == 1) dst[1] = make_uint2((unsigned)a0, EMPTY_ENTRY);
     __threadfence_block(); // the tail of a long x-list is read back by this block in pass B
     __syncthreads();
 
     const int nslab = nsy * nzc;
-    uint2 *sl_base = slist + (size_t)blockIdx.x * (size_t)nslab * SLOTS;
-    uint2 *ext_base = slist_ext + (size_t)blockIdx.x * (size_t)nslab * EXT_SLOTS;
-    for (int sl = wave; sl < nslab; sl += 4) {
-        const int sy = sl / nzc, zc = sl - sy * nzc;
-        const int zt_lo = zc * NW, zt_hi = zt_lo + NW - 1;
-        uint2 *out = sl_base + (size_t)sl * SLOTS;
-        uint2 *ext = ext_base + (size_t)sl * EXT_SLOTS;
-        int n = 0;
-        for (int i0 = 0; i0 < count; i0 += 64) {
-            const int i = i0 + lane;
-            uint2 en = make_uint2(0u, EMPTY_ENTRY);
-            if (i < count) {
-                if (i < XL_LDS) {
-                    en = xs[i];
-                } else { // beyond the LDS copy: this block's own stores, read back from L2 (agent scope bypasses L1)
-                    en.x = __hip_atomic_load(&dst[XL_HEADER + i].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    en.y = __hip_atomic_load(&dst[XL_HEADER + i].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const size_t xslab = (size_t)b * nsx + sx;
+    uint2 *sl_base = slist + xslab * (size_t)nslab * SLOTS;
+    uint2 *ext_base = slist_ext + xslab * (size_t)nslab * EXT_SLOTS;
+    const int nlds = count < XL_LDS ? count : XL_LDS;
+    // each wave builds four slab lines per pass over the x-list (one LDS read and one z test per round serve all four)
+    for (int g = 4 * wave; g < nslab; g += 16) {
+        int sy[4], zt_lo[4], zt_hi[4], n[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sl = g + q;
+            sy[q] = (sl < nslab) ? sl / nzc : 255; // 255: beyond the grid, matches no entry
+            zt_lo[q] = (sl - (sl / nzc) * nzc) * NW;
+            zt_hi[q] = zt_lo[q] + NW - 1;
+            n[q] = 0;
+        }
+        uint2 *ln = line[wave];
+        auto take = [&](const uint2 en) { // 64 x-list entries -> appended, in order, to the lines of the slabs they touch
+            const unsigned pk = en.y;
+            const int ylo = (int)(pk & 0xff), yhi = (int)((pk >> 8) & 0xff), zlo = (int)((pk >> 16) & 0xff), zhi = (int)(pk >> 24);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool mm = (ylo <= sy[q]) & (yhi >= sy[q]) & (zlo <= zt_hi[q]) & (zhi >= zt_lo[q]);
+                const unsigned long long mk = __ballot(mm);
+                const int pos = n[q] + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                if (mm & (pos < SLOTS - 1)) ln[q * SLOTS + 1 + pos] = en;
+                n[q] += __popcll(mk);
+                if (n[q] > SLOTS - 1) { // (wave-uniform, rare) the tail goes straight to the slab's extension line
+                    if (mm && pos >= SLOTS - 1 && pos < LINE_CAP) ext_base[(size_t)(g + q) * EXT_SLOTS + (pos - (SLOTS - 1))] = en;
                 }
             }
-            const unsigned pk = en.y;
-            const bool mm = ((int)(pk & 0xff) <= sy) && ((int)((pk >> 8) & 0xff) >= sy) &&
-                            ((int)((pk >> 16) & 0xff) <= zt_hi) && ((int)(pk >> 24) >= zt_lo);
-            const unsigned long long mk = __ballot(mm);
-            if (mm) {
-                const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                if (pos < SLOTS - 1) out[1 + pos] = en;
-                else if (pos < LINE_CAP) ext[pos - (SLOTS - 1)] = en;
-            }
-            n += __popcll(mk);
+        };
+        // (two loops: a global load inside the common LDS loop would put a vmcnt(0) wait, i.e. a wait for the
+        // previous round's stores, into every round)
+        for (int i0 = 0; i0 < nlds; i0 += 64) {
+            const int i = i0 + lane;
+            take(i < nlds ? xs[i] : make_uint2(0u, EMPTY_ENTRY));
         }
-        // more candidates than the line and its extension hold: the slab takes the x-list path
-        const unsigned hdr = (n > LINE_CAP) ? LINE_OVERFLOW : (unsigned)n;
-        if (lane == 0) out[0] = make_uint2(hdr, (unsigned)a0);
+        for (int i0 = XL_LDS; i0 < count; i0 += 64) { // beyond the LDS copy: this block's own stores, read back from L2
+            const int i = i0 + lane;
+            uint2 en = make_uint2(0u, EMPTY_ENTRY);
+            if (i < count) { // agent scope bypasses L1
+                en.x = __hip_atomic_load(&dst[XL_HEADER + i].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                en.y = __hip_atomic_load(&dst[XL_HEADER + i].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            take(en);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (g + q >= nslab) break;
+            // more candidates than the line and its extension hold: the slab takes the x-list path
+            const unsigned hdr = (n[q] > LINE_CAP) ? LINE_OVERFLOW : (unsigned)n[q];
+            if (lane == 0) {
+                ln[q * SLOTS] = make_uint2(hdr, (unsigned)a0);
+                if (n[q] > LINE_CAP) any_overflow = 1;
+            }
+            // the primary line leaves as one 512-B store (entries past the count are never read)
+            sl_base[(size_t)(g + q) * SLOTS + lane] = ln[q * SLOTS + lane]; // (nt: the line then misses L2 in the voxelize kernel, slower overall)
+        }
+    }
+    // the global x-list is only read by slabs on the x-list path: publish the LDS part when one exists
+    __syncthreads();
+    if (any_overflow) {
+        if (tid == 0) dst[0] = make_uint2((unsigned)count, EMPTY_ENTRY);
+        if (tid == 1) dst[1] = make_uint2((unsigned)a0, EMPTY_ENTRY);
+        const int nl = count < XL_LDS ? count : XL_LDS;
+        for (int i = tid; i < nl; i += 256) dst[XL_HEADER + i] = xs[i];
     }
 }
 
-hipError_t launch_xbin(const uint4 *bbox, const unsigned *xr, const int64_t *offsets, int32_t B, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
-                       uint2 *xlist, uint2 *slist, uint2 *slist_ext, hipStream_t s) {
-    if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(B * nsx)), dim3(256), 0, s, bbox, xr, offsets, nsx, nsy, nzc, NW, xlist,
-                       slist, slist_ext);
+hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int32_t b0, int32_t nb, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
+                       uint2 *xlist, uint2 *slist, uint2 *slist_ext, int *zero_counter, hipStream_t s) {
+    if (nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(nb * nsx)), dim3(256), 0, s, xp, offsets, b0, nsx, nsy, nzc, NW, xlist,
+                       slist, slist_ext, zero_counter);
     return hipGetLastError();
 }
 
@@ -659,11 +699,14 @@ __device__ __forceinline__ LaneCtx make_lane_ctx(int lane, int wave, int x0, int
 // candidates are entries 1..n_line. Stages their rows (slot = lane index) and walks them. Ends without a barrier.
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
 __device__ __forceinline__ void line_round(float2v (&acc)[(CT + 1) / 2], const uint2 Er, int e0, int n_line, int RW,
-                                           unsigned *un, const unsigned *__restrict__ rows, int64_t a0, int lane, int wave,
+                                           unsigned *un, const unsigned *__restrict__ rec, const unsigned *__restrict__ w,
+                                           int64_t a0, int lane, int wave,
                                            int NW, const LaneCtx &L, const VoxParams &P, const double *__restrict__ Tc,
                                            const float *__restrict__ kc) {
     constexpr int SW = 16 + (CT < 4 ? 4 : CT);
-    const int lane_word = lane < 16 ? lane : lane + L.cbase; // 0-15 record, 16.. the CT channel weights of the chunk
+    // lanes 0-15 fetch the record, lanes 16.. the CT channel weights of the chunk: one load instruction per row
+    const unsigned *src = lane < 16 ? rec + lane : w + (L.cbase + lane - 16);
+    const size_t stride = lane < 16 ? (size_t)16 : (size_t)P.w_stride;
     const bool stager = lane < 16 + CT;
     unsigned v[8];
 #pragma unroll
@@ -672,7 +715,7 @@ __device__ __forceinline__ void line_round(float2v (&acc)[(CT + 1) / 2], const u
         v[u] = 0u;
         if (sl < RW && e0 + sl >= 1 && e0 + sl <= n_line) {
             const int ai = __builtin_amdgcn_readlane((int)Er.x, sl & 63);
-            if (stager) v[u] = rows[(size_t)(a0 + ai) * (size_t)P.row_words + lane_word];
+            if (stager) v[u] = src[(size_t)(a0 + ai) * stride];
         }
     }
 #pragma unroll
@@ -694,7 +737,7 @@ __device__ __forceinline__ void line_round(float2v (&acc)[(CT + 1) / 2], const u
 
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
-    voxelize_kernel(const unsigned *__restrict__ rows, const uint2 *__restrict__ slist, const double *__restrict__ Tc,
+    voxelize_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist, const double *__restrict__ Tc,
                     const float *__restrict__ kc, float *__restrict__ out, int *__restrict__ overflow, const VoxParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -703,19 +746,14 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     const int NW = P.NW;
     unsigned *un = reinterpret_cast<unsigned *>(smem);
 
-    // grid = (T, Z): t = slab id, z = molecule * ncc + chunk. (MVX_XCD_SWAP=1 swaps the low three bits of t and z so
-    // that XCD k works through whole molecules; measured slower, kept as a knob.)
-    unsigned t = blockIdx.x, z = blockIdx.y;
-    if (P.xcd_swap && z < (gridDim.y & ~7u)) {
-        const unsigned tl = t & 7u, zl = z & 7u;
-        t = (t & ~7u) | zl;
-        z = (z & ~7u) | tl;
-    }
-    int b = (int)z, cc = 0;
+    // grid = (T, Z): t = slab id, z = (molecule - b0) * ncc + channel chunk
+    const unsigned t = blockIdx.x;
+    int b = (int)blockIdx.y, cc = 0;
     if (P.ncc > 1) {
-        b = (int)z / P.ncc;
-        cc = (int)z - b * P.ncc;
+        b = (int)blockIdx.y / P.ncc;
+        cc = (int)blockIdx.y - b * P.ncc;
     }
+    b += P.b0;
     // the slab's candidate line: {count, first atom}, then {atom index, packed ranges} per candidate
     const uint2 E = slist[((size_t)b * (size_t)gridDim.x + t) * SLOTS + lane];
     int sx, sy, zc;
@@ -733,18 +771,18 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     if (n_hdr >= (unsigned)RW) { // includes LINE_OVERFLOW: dense slab, left to voxelize_dense_kernel
         if (tid == 0) {
             const int pos = atomicAdd(overflow, 1);
-            overflow[1 + pos] = (int)(z * gridDim.x + t);
+            overflow[1 + pos] = (int)((unsigned)(b * P.ncc + cc) * gridDim.x + t);
         }
         return;
     }
     if (n_hdr > 0)
-        line_round<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, E, 0, (int)n_hdr, RW, un, rows, a0, lane, wave, NW, L, P, Tc, kc);
+        line_round<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, E, 0, (int)n_hdr, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
     write_slab<CT>(acc, n_hdr > 0, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, cc * CT, x0, y0, z0, out, P);
 }
 
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
 __global__ void __launch_bounds__(1024)
-    voxelize_dense_kernel(const unsigned *__restrict__ rows, const uint2 *__restrict__ xlist,
+    voxelize_dense_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ xlist,
                           const uint2 *__restrict__ slist, const uint2 *__restrict__ slist_ext,
                           const int64_t *__restrict__ offsets, const double *__restrict__ Tc,
                           const float *__restrict__ kc, float *__restrict__ out, const int *__restrict__ overflow,
@@ -764,8 +802,8 @@ __global__ void __launch_bounds__(1024)
     const int count = overflow[0];
     const int RW = 8 * NW < 64 ? 8 * NW : 64;
 
-    for (int w = blockIdx.x; w < count; w += gridDim.x) {
-        const unsigned id = (unsigned)overflow[1 + w];
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        const unsigned id = (unsigned)overflow[1 + item];
         const unsigned z = id / T, t = id - z * T;
         int b = (int)z, cc = 0;
         if (P.ncc > 1) {
@@ -795,14 +833,15 @@ __global__ void __launch_bounds__(1024)
                 const int e = e0 + lane;
                 uint2 Er = make_uint2(0u, EMPTY_ENTRY);
                 if (lane < RW && e <= n_line) Er = (e < SLOTS) ? line[e] : ext[e - SLOTS];
-                line_round<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, Er, e0, n_line, RW, un, rows, a0, lane, wave, NW, L, P, Tc, kc);
+                line_round<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, Er, e0, n_line, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
             }
         } else {
             // x-list path: more candidates than a line and its extension hold
             const int64_t nmol = offsets[b + 1] - offsets[b];
             const uint2 *__restrict__ xl = xlist + ((size_t)a0 + 2 * (size_t)b) * P.nsx + (size_t)sx * (size_t)(nmol + XL_HEADER);
             const int nx = (int)xl[0].x + XL_HEADER;
-            const int lane_word = lane < 16 ? lane : lane + L.cbase;
+            const unsigned *src = lane < 16 ? rec + lane : w + (L.cbase + lane - 16);
+            const size_t stride = lane < 16 ? (size_t)16 : (size_t)P.w_stride;
             const bool stager = lane < 16 + CT;
             for (int base = 0; base < nx; base += LCAP) {
                 __syncthreads(); // list / candidate rows of the previous round consumed
@@ -831,7 +870,7 @@ __global__ void __launch_bounds__(1024)
                     const int n = (nl - c0) < P.dcap ? (nl - c0) : P.dcap; // rows staged this round
                     if (c0 > 0) __syncthreads();
                     for (int j = wave; j < n; j += NW)
-                        if (stager) un[j * SW + lane] = rows[(size_t)(a0 + list[c0 + j]) * (size_t)P.row_words + lane_word];
+                        if (stager) un[j * SW + lane] = src[(size_t)(a0 + list[c0 + j]) * stride];
                     __syncthreads();
                     for (int jb = 0; jb < n; jb += 64) {
                         const int j = jb + lane;
@@ -910,35 +949,48 @@ static hipError_t launch_dense(const VoxArgs &a, hipStream_t s) {
     auto kern = &voxelize_dense_kernel<CT, GAUSS, CHANWISE, LANE_RANGE>;
     hipError_t e = raise_lds_limit(kern, lds, raised);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(512), dim3(p.NW * 64), lds, s, a.rows, a.xlist, a.slist, a.slist_ext, a.offsets, a.Tc,
+    hipLaunchKernelGGL(kern, dim3(512), dim3(p.NW * 64), lds, s, a.rec, a.w, a.xlist, a.slist, a.slist_ext, a.offsets, a.Tc,
                        a.kc, a.out, a.overflow, a.p, (unsigned)(p.nzc * p.nsy * p.nsx));
     return hipGetLastError();
 }
 
 struct LaunchFn {
     const VoxArgs &a;
+    int32_t nb;
     hipStream_t s;
     template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
     hipError_t operator()() const {
         const VoxParams &p = a.p;
-        if (p.B <= 0) return hipSuccess;
-        if ((long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
+        if (nb <= 0) return hipSuccess;
+        if ((long long)nb * p.ncc > 65535) return hipErrorInvalidConfiguration;
         static size_t raised = 0;
-        static const size_t lds_pad = std::getenv("MVX_LDS_PAD") ? (size_t)std::atoi(std::getenv("MVX_LDS_PAD")) : 0; // experiments
-        const size_t lds = voxelize_lds_bytes(CT, p.NW) + lds_pad;
+        const size_t lds = voxelize_lds_bytes(CT, p.NW);
         auto kern = &voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>;
         hipError_t e = raise_lds_limit(kern, lds, raised);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(p.B * p.ncc)), dim3(p.NW * 64), lds, s,
-                           a.rows, a.slist, a.Tc, a.kc, a.out, a.overflow, a.p);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), lds, s,
+                           a.rec, a.w, a.slist, a.Tc, a.kc, a.out, a.overflow, a.p);
+        return hipGetLastError();
+    }
+};
+
+struct DenseFn {
+    const VoxArgs &a;
+    hipStream_t s;
+    template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
+    hipError_t operator()() const {
         return launch_dense<CT, GAUSS, CHANWISE, LANE_RANGE>(a, s);
     }
 };
 
-hipError_t launch_voxelize(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {
+hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {
     KernelKey k{ct, gauss, chanwise, chanwise ? true : lane_range, a.p.NW <= 8 ? 512 : 1024};
-    return for_kernel(k, LaunchFn{a, s});
+    return for_kernel(k, LaunchFn{a, nb, s});
+}
+
+hipError_t launch_voxelize_dense(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {
+    KernelKey k{ct, gauss, chanwise, chanwise ? true : lane_range, a.p.NW <= 8 ? 512 : 1024};
+    return for_kernel(k, DenseFn{a, s});
 }
 
 hipError_t configure_kernels() { return hipSuccess; }

@@ -310,7 +310,7 @@ def test_medium_density_multi_round_slab_lines(mv):
 
 
 def test_long_x_list_beyond_lds_copy(mv):
-    """An x-slab list longer than the binning pass's LDS copy (2048 entries): its tail is re-read from L2."""
+    """An x-slab list longer than the binning pass's LDS copy (1024 entries): its tail is re-read from L2."""
     from oracle import c_oracle
 
     rng = np.random.default_rng(13)
@@ -340,6 +340,41 @@ def test_ragged_batch_with_one_large_molecule(mv):
     for b, n in enumerate(sizes):
         ref = c_oracle.voxelize(coords[b], types[b], 1.0, dimension=D, density="binary", num_channels=3) if n else 0
         assert np.array_equal(out[b], ref + np.zeros_like(out[b])), b
+
+
+def test_pipelined_chunks_match_single_stream(mv, monkeypatch):
+    """Batches of >= 8 molecules are cut into chunks whose pre-pass runs on a side stream (MVX_PIPELINE); results
+    must not depend on the chunk count, and every chunk count must match the oracle (ragged sizes, empty
+    molecules, a dense cluster that takes the overflow list, random transforms)."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(21)
+    D = 32
+    W_ = 0.5 * (D - 1)
+    sizes = [40, 0, 700, 3, 1500, 0, 0, 90, 2500, 1, 33, 400, 0, 64, 65, 1000, 7]
+    coords = [rng.uniform(-W_ / 2 - 1, W_ / 2 + 1, (n, 3)) for n in sizes]
+    coords[4] = rng.normal(0.0, 0.4, (sizes[4], 3))  # dense cluster: hundreds of candidates per slab
+    feats = [rng.random((n, 7)).astype(np.float32) for n in sizes]
+    radii = [rng.uniform(0.8, 1.6, n).astype(np.float32) for n in sizes]
+    offsets = np.cumsum([0] + sizes)
+    outs = {}
+    for chunks in (1, 2, 3, 5):
+        monkeypatch.setenv("MVX_PIPELINE", str(chunks))
+        v = mv.create_voxelizer(0.5, D, "atom-wise", "gaussian", "hip", sigma=0.7, output="numpy")
+        for _ in range(2):  # the second call reuses the workspace the first call's launches read
+            outs[chunks] = v.forward_batch(np.concatenate(coords), offsets, None, np.concatenate(feats), np.concatenate(radii))
+    for chunks in (2, 3, 5):
+        assert np.array_equal(outs[chunks], outs[1]), chunks
+    for b, n in enumerate(sizes):
+        if n == 0:
+            assert not outs[1][b].any()
+            continue
+        ref = c_oracle.voxelize(coords[b], feats[b], radii[b], dimension=D, radii_type="atom-wise", density="gaussian", sigma=0.7)
+        if b == 4:  # sums of hundreds of terms: the 1e-5 absolute bar scales with the magnitude (float32 sums)
+            assert np.array_equal(outs[1][b] != 0, ref != 0)
+            assert np.abs(outs[1][b] - ref).max() <= GAUSS_TOL * max(1.0, float(np.abs(ref).max()))
+        else:
+            _compare(outs[1][b], ref, exact=False)
 
 
 def test_transform_objects_on_device(mv):
