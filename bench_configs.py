@@ -56,9 +56,79 @@ def run(name, wl, batch_ids, steps, warmup=3):
                 ms_per_call=1e3 * el / steps, molecules_per_s=B * steps / el)
 
 
+def harness_inputs():
+    """The 10gs complex as test/test_time_numpy.py:24-50 voxelizes it, restated without RDKit: ligand + whole protein
+    heavy atoms, centre = ligand centroid, channels = {C, N, O, S, other} x {ligand, protein} (the reference's
+    getters add bond channels on top; atoms only here)."""
+    pc = np.load(os.path.join(ROOT, "tests", "golden", "pointcloud_10gs.npz"))
+    coords = np.concatenate([pc["ligand_xyz"], pc["protein_xyz"]])
+    types = np.concatenate([pc["ligand_types"].astype(np.int64), pc["protein_types"].astype(np.int64) + 5])
+    features = np.zeros((coords.shape[0], 10), dtype=np.float32)
+    features[np.arange(coords.shape[0]), types] = 1.0
+    return coords, pc["ligand_xyz"].mean(axis=0), types, features
+
+
+def harness(voxelizer, batch_size=16, num_iteration=25, num_trial=5, log=print):
+    """test/test_time_numpy.py:11-110 restated for any backend object: per-molecule `forward` calls with random
+    translation 0.5 and random rotation into `out_grid=grid[i]`, 16 x 25 x 5, seconds per run for single / types /
+    features. Returns {mode: seconds per run}."""
+    coords, center, types, features = harness_inputs()
+    coords, center = voxelizer.asarray(coords, "coords"), voxelizer.asarray(center, "center")
+    types_, features_ = voxelizer.asarray(types, "types"), voxelizer.asarray(features, "features")
+    grid = voxelizer.get_empty_grid(10, batch_size)
+    single_grid = voxelizer.get_empty_grid(1, batch_size)
+
+    def run_test(g, channels, tr=0.5, rot=True):
+        for i in range(g.shape[0]):
+            voxelizer.forward(coords, center, channels, 1.0, tr, rot, out_grid=g[i])
+        return g
+
+    def sync():
+        if getattr(voxelizer, "LIB", "") == "HIP":
+            import torch
+
+            torch.cuda.synchronize()
+
+    # sanity check of the reference harness (:52-69): reproducible, and types == one-hot features
+    t = np.array(run_test(grid, types_, 0.0, False).tolist())
+    f = np.array(run_test(grid, features_, 0.0, False).tolist())
+    assert np.less(np.abs(t - t[0]), 1e-5).all() and np.less(np.abs(f - f[0]), 1e-5).all(), "REPRODUCTION FAIL"
+    assert np.less(np.abs(t[0] - f[0]), 1e-5).all(), "REPRODUCTION FAIL"
+    out = {}
+    for mode, g, ch in (("single", single_grid, None), ("types", grid, types_), ("features", grid, features_)):
+        sync()
+        st = time.time()
+        for _ in range(num_trial):
+            for _ in range(num_iteration):
+                run_test(g, ch)
+        sync()
+        out[mode] = (time.time() - st) / batch_size / num_iteration / num_trial
+        log(f"{mode}: time per run {out[mode]:.3e} s")
+    return out
+
+
+def pcie_inclusive(steps=5):
+    """cfg-2 through the numpy-in / numpy-out form of the boundary: host arrays up, the grid back over PCIe."""
+    import molvoxel_amd
+    from molvoxel_amd import workloads as W
+
+    wl = W.cfg2(batch=8)
+    vox = molvoxel_amd.create_voxelizer(0.5, 64, "scalar", "gaussian", library="hip", output="numpy")
+    coords = np.concatenate([wl.coords[i] for i in range(8)])
+    feats = np.concatenate([wl.channels[i] for i in range(8)])
+    offsets = np.arange(9, dtype=np.int64) * 4000
+    vox.forward_batch(coords, offsets, None, feats, 1.0)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        vox.forward_batch(coords, offsets, None, feats, 1.0)
+    el = time.perf_counter() - t0
+    return dict(config="cfg2 x8, numpy in -> numpy out (PCIe inclusive)", molecules_per_s=8 * steps / el, ms_per_molecule=1e3 * el / steps / 8)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--harness", action="store_true", help="also run the test_time_numpy.py loop (16 x 25 x 5) on the hip backend")
     args = ap.parse_args()
     from molvoxel_amd import workloads as W
 
@@ -76,8 +146,14 @@ def main():
     w5 = W.cfg5(batch=4)
     rows.append(run("cfg5 N=10000 C=32 128^3 atom-wise (single call)", w5, [0], args.steps))
     rows.append(run("cfg5 N=10000 C=32 128^3 atom-wise x4", w5, [0, 1, 2, 3], args.steps))
+    rows.append(pcie_inclusive())
     for r in rows:
         print(json.dumps(r))
+    if args.harness:
+        import molvoxel_amd
+
+        res = harness(molvoxel_amd.create_voxelizer(0.5, 48, library="hip"), log=lambda *_: None)
+        print(json.dumps(dict(config="test_time harness 10gs complex 48^3 (16 x 25 x 5), seconds per run", **res)))
 
 
 if __name__ == "__main__":

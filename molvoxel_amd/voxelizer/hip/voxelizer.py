@@ -66,6 +66,7 @@ class Voxelizer(BaseVoxelizer):
         self._lib = _lib.load()
         self._device_index = self._resolve_device(device)
         self._handle = _lib.Handle()
+        self._types_cache = None
         cfg = _lib.MvxConfig(
             float(resolution),
             float(getattr(self, "_sigma", 0.5)),
@@ -309,12 +310,25 @@ class Voxelizer(BaseVoxelizer):
             C.cast(C.byref(xf), C.c_void_p), self._ptr(buf), in_kind, out_kind, self._stream()))
         return self._finish_out(buf, ret, how)
 
+    def _types_extent(self, types):
+        """(min, max) of the type indices. For a device tensor this costs a kernel and a synchronisation, so the
+        answer is remembered for as long as the same tensor is passed unmodified (torch bumps `_version` on every
+        in-place write) - the per-molecule loop of test/test_time_numpy.py:11-15 asks thousands of times."""
+        if not _is_torch(types):
+            return int(types.min()), int(types.max())
+        key = (types.data_ptr(), types.numel(), types._version, str(types.dtype))
+        if self._types_cache is None or self._types_cache[0] != key:
+            lo, hi = torch.aminmax(types)
+            self._types_cache = (key, int(lo), int(hi))
+        return self._types_cache[1], self._types_cache[2]
+
     def _check_args_types(self, coords, types, radii, out_grid=None):
         V = coords.shape[0]
-        C_ = int(types.max()) + 1
+        tmin, tmax = self._types_extent(types)
+        C_ = tmax + 1
         D = H = W = self.dimension
         assert tuple(types.shape) == (V,), f"types does not match dimension: {tuple(types.shape)} vs {(V,)}"
-        assert int(types.min()) >= 0, "types must be non-negative channel indices"
+        assert tmin >= 0, "types must be non-negative channel indices"
         if self.is_radii_type_scalar:
             assert _np_isscalar(radii), "the radii type of voxelizer is `scalar`, radii should be scalar"
         elif self.is_radii_type_channel_wise:

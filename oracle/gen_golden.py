@@ -321,6 +321,7 @@ def main():
     pc = dict(
         ligand_xyz=lig_xyz, ligand_types=lig_t, ligand_feat5=feat5, pocket_xyz=prot_xyz[near],
         pocket_types=element_types([s for s, k in zip(prot_sym, near) if k]),
+        protein_xyz=prot_xyz, protein_types=element_types(prot_sym),  # the whole chain: what test_time_*.py voxelizes
     )
     np.savez_compressed(os.path.join(GOLD, "pointcloud_10gs.npz"), **pc)
     print("10gs: ligand heavy", lig_xyz.shape[0], "protein heavy", prot_xyz.shape[0], "pocket", int(near.sum()))
