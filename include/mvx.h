@@ -30,6 +30,8 @@
  *     3. float32( float32(sqrt_f64((dx^2+dy^2)+dz^2)) / float32(r) ) <= 1          :544-555
  *   with value 1 (binary) or exp(-0.5*(dr/sigma)^2) in float32 (gaussian)            :557-560.
  *   Membership (1-3) is reproduced exactly; gaussian values agree to ~1e-6.
+ *   A precision-64 handle keeps step 3 and the values in float64, as the reference does with
+ *   precision=64 (:33-34): sqrt_f64(d2) / r <= 1, exp(-0.5*((dr/sigma)^2)) in float64; values agree to ~1e-15.
  */
 #ifndef MVX_H
 #define MVX_H
@@ -40,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MVX_VERSION 100 /* 0.1.0 */
+#define MVX_VERSION 110 /* 0.1.1: mvx_config.precision, mvx_real */
 
 typedef enum mvx_status {
     MVX_OK = 0,
@@ -54,8 +56,8 @@ enum mvx_memkind { MVX_HOST = 0, MVX_DEVICE = 1 };
 enum mvx_density { MVX_GAUSSIAN = 0, MVX_BINARY = 1 }; /* base/voxelizer.py:13  DENSITY_TYPE_LIST */
 enum mvx_radii {                                         /* base/voxelizer.py:12  RADII_TYPE_LIST */
     MVX_RADII_SCALAR = 0,  /* one python float for every atom */
-    MVX_RADII_ATOM = 1,    /* float32 (N,)   "atom-wise"    */
-    MVX_RADII_CHANNEL = 2  /* float32 (C,)   "channel-wise" */
+    MVX_RADII_ATOM = 1,    /* mvx_real (N,)  "atom-wise"    */
+    MVX_RADII_CHANNEL = 2  /* mvx_real (C,)  "channel-wise" */
 };
 enum mvx_xform_flags {
     MVX_XF_CENTER = 1,    /* p = p - center first */
@@ -77,7 +79,14 @@ typedef struct mvx_config {
                           <= 0 means the reference default 8; >= dimension means one block (no block cull) */
     int32_t density;   /* enum mvx_density */
     int32_t device;    /* HIP device ordinal */
+    int32_t precision; /* 32 (or 0) | 64: the `precision` argument of Voxelizer.__init__ (numpy/voxelizer.py:28,33-34):
+                          element type of features, radii and the grid, and the type distances, densities and sums
+                          are evaluated in */
+    int32_t reserved;  /* 0 */
 } mvx_config;
+
+/* float for a precision-32 handle, double for a precision-64 handle (the reference's `self.fp`). */
+typedef void mvx_real;
 
 /*
  * Per-molecule rigid transform applied on the device before voxelization, in exactly the
@@ -108,7 +117,7 @@ int mvx_set_density(mvx_handle *h, int32_t density, double sigma);
  * Batched entry points: B molecules stored back to back, molecule b owning atoms
  * [offsets[b], offsets[b+1]). `offsets` (B+1 int64) and `xforms` (B records, may be NULL =
  * identity) are host pointers. coords / features / types / radii share `in_kind`.
- * out is (B, C, D, D, D) float32, fully overwritten (zeros included), `out_kind` tagged.
+ * out is (B, C, D, D, D) mvx_real, fully overwritten (zeros included), `out_kind` tagged.
  *
  *   radii_type SCALAR : radius = radius_scalar for every atom (radii ignored, may be NULL)
  *              ATOM   : radii[sumN]
@@ -117,33 +126,33 @@ int mvx_set_density(mvx_handle *h, int32_t density, double sigma);
  *                       own radius and culls with max(radii) (numpy/voxelizer.py:138,213-224).
  *
  * mvx_forward_features_batch replaces Voxelizer.forward_features (numpy/voxelizer.py:97-169)
- *   features: (sumN, C) float32 row-major.
+ *   features: (sumN, C) mvx_real row-major.
  * mvx_forward_types_batch replaces Voxelizer.forward_types (numpy/voxelizer.py:240-315)
  *   types: (sumN,) int32 in [0, C); out has C channels (C may exceed max(types)+1, numpy/voxelizer.py:337).
  * mvx_forward_single_batch replaces Voxelizer.forward_single (numpy/voxelizer.py:370-436)
  *   out is (B, 1, D, D, D).
  */
-int mvx_forward_features_batch(mvx_handle *h, const double *coords, const float *features, const float *radii,
+int mvx_forward_features_batch(mvx_handle *h, const double *coords, const mvx_real *features, const mvx_real *radii,
                                double radius_scalar, int32_t radii_type, const int64_t *offsets,
-                               const mvx_xform *xforms, int32_t B, int32_t C, float *out, int32_t in_kind,
+                               const mvx_xform *xforms, int32_t B, int32_t C, mvx_real *out, int32_t in_kind,
                                int32_t out_kind, void *stream);
-int mvx_forward_types_batch(mvx_handle *h, const double *coords, const int32_t *types, const float *radii,
+int mvx_forward_types_batch(mvx_handle *h, const double *coords, const int32_t *types, const mvx_real *radii,
                             double radius_scalar, int32_t radii_type, const int64_t *offsets,
-                            const mvx_xform *xforms, int32_t B, int32_t C, float *out, int32_t in_kind,
+                            const mvx_xform *xforms, int32_t B, int32_t C, mvx_real *out, int32_t in_kind,
                             int32_t out_kind, void *stream);
-int mvx_forward_single_batch(mvx_handle *h, const double *coords, const float *radii, double radius_scalar,
+int mvx_forward_single_batch(mvx_handle *h, const double *coords, const mvx_real *radii, double radius_scalar,
                              int32_t radii_type, const int64_t *offsets, const mvx_xform *xforms, int32_t B,
-                             float *out, int32_t in_kind, int32_t out_kind, void *stream);
+                             mvx_real *out, int32_t in_kind, int32_t out_kind, void *stream);
 
 /* Single-molecule forms (B = 1, xform may be NULL): the reference's per-call signature. */
-int mvx_forward_features(mvx_handle *h, const double *coords, const float *features, const float *radii,
+int mvx_forward_features(mvx_handle *h, const double *coords, const mvx_real *features, const mvx_real *radii,
                          double radius_scalar, int32_t radii_type, int64_t N, int32_t C, const mvx_xform *xform,
-                         float *out, int32_t in_kind, int32_t out_kind, void *stream);
-int mvx_forward_types(mvx_handle *h, const double *coords, const int32_t *types, const float *radii,
+                         mvx_real *out, int32_t in_kind, int32_t out_kind, void *stream);
+int mvx_forward_types(mvx_handle *h, const double *coords, const int32_t *types, const mvx_real *radii,
                       double radius_scalar, int32_t radii_type, int64_t N, int32_t C, const mvx_xform *xform,
-                      float *out, int32_t in_kind, int32_t out_kind, void *stream);
-int mvx_forward_single(mvx_handle *h, const double *coords, const float *radii, double radius_scalar,
-                       int32_t radii_type, int64_t N, const mvx_xform *xform, float *out, int32_t in_kind,
+                      mvx_real *out, int32_t in_kind, int32_t out_kind, void *stream);
+int mvx_forward_single(mvx_handle *h, const double *coords, const mvx_real *radii, double radius_scalar,
+                       int32_t radii_type, int64_t N, const mvx_xform *xform, mvx_real *out, int32_t in_kind,
                        int32_t out_kind, void *stream);
 
 /*

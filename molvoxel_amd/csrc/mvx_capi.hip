@@ -159,13 +159,13 @@ struct RunArgs {
     int mode;
     const double *coords;
     const void *channels; // float features (sumN, C) | int32 types (sumN) | null
-    const float *radii;
+    const void *radii; // float, or double for a precision-64 handle (like features and out)
     double radius_scalar;
     int radii_type;
     const int64_t *offsets;
     const mvx_xform *xforms;
     int B, C;
-    float *out;
+    void *out;
     int in_kind, out_kind;
     hipStream_t stream;
 };
@@ -196,19 +196,21 @@ int run(mvx_handle *h, const RunArgs &r) {
     const Geom &g = h->g;
     const int D = g.D;
     const size_t D3 = (size_t)D * D * D;
-    const size_t out_bytes = (size_t)r.B * r.C * D3 * sizeof(float);
+    const bool f64 = (h->cfg.precision == 64);
+    const size_t esz = f64 ? sizeof(double) : sizeof(float); // element size of features, radii and the grid
+    const size_t out_bytes = (size_t)r.B * r.C * D3 * esz;
 
     // ---- host-side metadata (+ host-resident inputs) -> one pinned slot -> device ----------------
     const size_t off_bytes = align_up((size_t)(r.B + 1) * sizeof(int64_t), 16);
     const size_t xf_bytes = r.xforms ? align_up((size_t)r.B * sizeof(mvx_xform), 16) : 0;
     const bool host_in = (r.in_kind == MVX_HOST);
-    const size_t chan_elem = (r.mode == MODE_FEATURES) ? (size_t)r.C * sizeof(float) : (r.mode == MODE_TYPES ? sizeof(int32_t) : 0);
+    const size_t chan_elem = (r.mode == MODE_FEATURES) ? (size_t)r.C * esz : (r.mode == MODE_TYPES ? sizeof(int32_t) : 0);
     const size_t co_bytes = host_in ? align_up((size_t)total * 3 * sizeof(double), 16) : 0;
     const size_t ch_bytes = host_in ? align_up((size_t)total * chan_elem, 16) : 0;
     size_t rad_count = 0;
     if (r.radii_type == MVX_RADII_ATOM) rad_count = (size_t)total;
     else if (r.radii_type == MVX_RADII_CHANNEL) rad_count = (size_t)r.C;
-    const size_t ra_bytes = host_in ? align_up(rad_count * sizeof(float), 16) : 0;
+    const size_t ra_bytes = host_in ? align_up(rad_count * esz, 16) : 0;
 
     PinnedSlot *slot = nullptr;
     int rc = acquire_slot(h, off_bytes + xf_bytes + co_bytes + ch_bytes + ra_bytes, &slot);
@@ -234,7 +236,7 @@ int run(mvx_handle *h, const RunArgs &r) {
 
     const double *d_coords = r.coords;
     const void *d_chan = r.channels;
-    const float *d_radii = r.radii;
+    const void *d_radii = r.radii;
     if (host_in && total > 0) {
         char *q = pin + off_bytes + xf_bytes;
         if ((rc = ensure(h->in_coords, co_bytes))) return rc;
@@ -253,15 +255,15 @@ int run(mvx_handle *h, const RunArgs &r) {
     if (host_in && rad_count > 0) {
         char *q = pin + off_bytes + xf_bytes + co_bytes + ch_bytes;
         if ((rc = ensure(h->in_radii, ra_bytes))) return rc;
-        std::memcpy(q, r.radii, rad_count * sizeof(float));
+        std::memcpy(q, r.radii, rad_count * esz);
         HIP_TRY(hipMemcpyAsync(h->in_radii.p, q, ra_bytes, hipMemcpyHostToDevice, s));
-        d_radii = reinterpret_cast<const float *>(h->in_radii.p);
+        d_radii = h->in_radii.p;
     }
 
-    float *d_out = r.out;
+    void *d_out = r.out;
     if (r.out_kind == MVX_HOST) {
         if ((rc = ensure(h->out_stage, out_bytes))) return rc;
-        d_out = reinterpret_cast<float *>(h->out_stage.p);
+        d_out = h->out_stage.p;
     } else if ((reinterpret_cast<uintptr_t>(r.out) & 15u) != 0) {
         return fail(MVX_ERR_INVALID, "device out pointer must be 16-byte aligned");
     }
@@ -269,27 +271,31 @@ int run(mvx_handle *h, const RunArgs &r) {
     // ---- workspace --------------------------------------------------------------------------------
     const size_t n_alloc = (size_t)std::max<int64_t>(total, 1);
     // channels per workgroup (register accumulators per lane); more channels -> several channel chunks
-    const int ct = pick_ct(std::min(r.C, h->max_ct));
+    const int ct = pick_ct(std::min(r.C, f64 ? std::min(h->max_ct, 16) : h->max_ct)); // float64 rows: <= 16 channels
     const int ncc = (r.C + ct - 1) / ct;
     const int Cpad = (ncc > 1) ? ncc * ct : (ct < 4 ? 4 : ct); // channel weights per atom, zero padded
     // feature rows that already are Cpad wide are read in place; anything else (one-hot types, 1, padding) is packed
     const bool direct_w = (r.mode == MODE_FEATURES && r.C == Cpad);
     if ((rc = ensure(h->rec, n_alloc * sizeof(AtomRec)))) return rc;
-    if (!direct_w && (rc = ensure(h->wbuf, n_alloc * (size_t)Cpad * sizeof(float)))) return rc;
+    if (!direct_w && (rc = ensure(h->wbuf, n_alloc * (size_t)Cpad * esz))) return rc;
     if ((rc = ensure(h->xp, n_alloc * sizeof(uint2)))) return rc;
 
     const bool gauss = (h->cfg.density == MVX_GAUSSIAN);
     const bool chanwise = (r.radii_type == MVX_RADII_CHANNEL && r.mode == MODE_FEATURES);
-    float *d_rmax = nullptr;
+    void *d_rmax = nullptr;
     double *d_Tc = nullptr;
     float *d_kc = nullptr;
     if (chanwise) {
         const size_t tc_off = 16, kc_off = tc_off + align_up((size_t)r.C * sizeof(double), 16);
         if ((rc = ensure(h->aux, kc_off + (size_t)r.C * sizeof(float)))) return rc;
-        d_rmax = reinterpret_cast<float *>(h->aux.p);
+        d_rmax = h->aux.p;
         d_Tc = reinterpret_cast<double *>((char *)h->aux.p + tc_off);
         d_kc = reinterpret_cast<float *>((char *)h->aux.p + kc_off);
-        HIP_TRY(launch_chan_aux(d_radii, r.C, h->cfg.density, h->sigma32, d_rmax, d_Tc, d_kc, s));
+        if (f64)
+            HIP_TRY(launch_chan_aux64(static_cast<const double *>(d_radii), r.C, static_cast<double *>(d_rmax), d_Tc, s));
+        else
+            HIP_TRY(launch_chan_aux(static_cast<const float *>(d_radii), r.C, h->cfg.density, h->sigma32,
+                                    static_cast<float *>(d_rmax), d_Tc, d_kc, s));
     }
 
     // ---- prep -------------------------------------------------------------------------------------
@@ -297,12 +303,13 @@ int run(mvx_handle *h, const RunArgs &r) {
     pa.coords = d_coords;
     pa.radii = d_radii;
     pa.types = (r.mode == MODE_TYPES) ? reinterpret_cast<const int32_t *>(d_chan) : nullptr;
-    pa.features = (r.mode == MODE_FEATURES) ? reinterpret_cast<const float *>(d_chan) : nullptr;
+    pa.features = (r.mode == MODE_FEATURES) ? d_chan : nullptr;
     pa.mode = r.mode;
     pa.Cpad = Cpad;
     pa.offsets = d_off;
     pa.xforms = d_xf;
     pa.chan_aux = d_rmax;
+    pa.precision = f64 ? 64 : 32;
     pa.first = 0;
     pa.total = total;
     pa.B = r.B;
@@ -315,7 +322,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     pa.sigma32 = h->sigma32;
     pa.g = g;
     pa.rec = reinterpret_cast<AtomRec *>(h->rec.p);
-    pa.wbuf = direct_w ? nullptr : reinterpret_cast<float *>(h->wbuf.p);
+    pa.wbuf = direct_w ? nullptr : h->wbuf.p;
     pa.xp = reinterpret_cast<uint2 *>(h->xp.p);
 
     // ---- voxelize ---------------------------------------------------------------------------------
@@ -367,7 +374,8 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.offsets = d_off;
     va.xlist = reinterpret_cast<const uint2 *>(h->xlist.p);
     va.p.ncc = ncc;
-    va.p.dcap = voxelize_dcap(ct, NW);
+    va.p.dcap = f64 ? 64 : voxelize_dcap(ct, NW);
+    va.p.sigma = h->cfg.sigma;
     va.p.vec_store = (D % 4 == 0) ? 1 : 0;
     va.p.store_kind = h->store_kind;
     // a sub-tile lies inside one reference block when its edges divide blockdim (or there is a single block):
@@ -403,7 +411,7 @@ int run(mvx_handle *h, const RunArgs &r) {
                             k == 0 ? va.overflow : nullptr, pre));
         if (nchunk > 1) HIP_TRY(hipEventRecord(h->ev_pre[k], pre));
     }
-    for (int k = 0; k < nchunk; ++k) {
+    for (int k = 0; k < nchunk && !f64; ++k) {
         const int b0 = (int)((int64_t)r.B * k / nchunk), b1 = (int)((int64_t)r.B * (k + 1) / nchunk);
         if (nchunk > 1) HIP_TRY(hipStreamWaitEvent(s, h->ev_pre[k], 0));
         const bool timed = h->profiling && h->ev_count < MVX_PROFILE_RING;
@@ -415,6 +423,17 @@ int run(mvx_handle *h, const RunArgs &r) {
             ++h->ev_count;
         }
         if (k == nchunk - 1) HIP_TRY(launch_voxelize_dense(va, ct, gauss, chanwise, lane_range, s));
+    }
+    if (f64) { // float64 grids: one launch of the general slab loop over the whole batch
+        for (int k = 0; k < nchunk && nchunk > 1; ++k) HIP_TRY(hipStreamWaitEvent(s, h->ev_pre[k], 0));
+        const bool timed = h->profiling && h->ev_count < MVX_PROFILE_RING;
+        if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count], s));
+        va.p.b0 = 0;
+        HIP_TRY(launch_voxelize64(va, ct, gauss, chanwise, lane_range, s));
+        if (timed) {
+            HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count + 1], s));
+            ++h->ev_count;
+        }
     }
 
     HIP_TRY(hipEventRecord(slot->done, s));
@@ -457,6 +476,8 @@ int mvx_create(const mvx_config *cfg, mvx_handle **out) {
     if (cfg->dimension < 1 || cfg->dimension > 1020) return fail(MVX_ERR_INVALID, "dimension must be in [1, 1020]");
     if (cfg->density != MVX_GAUSSIAN && cfg->density != MVX_BINARY) return fail(MVX_ERR_INVALID, "bad density");
     if (cfg->density == MVX_GAUSSIAN && !(cfg->sigma > 0.0)) return fail(MVX_ERR_INVALID, "sigma must be > 0");
+    if (cfg->precision != 0 && cfg->precision != 32 && cfg->precision != 64)
+        return fail(MVX_ERR_INVALID, "precision must be 32 or 64"); // numpy/voxelizer.py:33
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -518,50 +539,50 @@ int mvx_set_density(mvx_handle *h, int32_t density, double sigma) {
     return MVX_OK;
 }
 
-int mvx_forward_features_batch(mvx_handle *h, const double *coords, const float *features, const float *radii,
+int mvx_forward_features_batch(mvx_handle *h, const double *coords, const void *features, const void *radii,
                                double radius_scalar, int32_t radii_type, const int64_t *offsets,
-                               const mvx_xform *xforms, int32_t B, int32_t C, float *out, int32_t in_kind,
+                               const mvx_xform *xforms, int32_t B, int32_t C, void *out, int32_t in_kind,
                                int32_t out_kind, void *stream) {
     RunArgs r{MODE_FEATURES, coords, features, radii, radius_scalar, radii_type, offsets, xforms, B, C, out,
               in_kind, out_kind, reinterpret_cast<hipStream_t>(stream)};
     return run(h, r);
 }
 
-int mvx_forward_types_batch(mvx_handle *h, const double *coords, const int32_t *types, const float *radii,
+int mvx_forward_types_batch(mvx_handle *h, const double *coords, const int32_t *types, const void *radii,
                             double radius_scalar, int32_t radii_type, const int64_t *offsets,
-                            const mvx_xform *xforms, int32_t B, int32_t C, float *out, int32_t in_kind,
+                            const mvx_xform *xforms, int32_t B, int32_t C, void *out, int32_t in_kind,
                             int32_t out_kind, void *stream) {
     RunArgs r{MODE_TYPES, coords, types, radii, radius_scalar, radii_type, offsets, xforms, B, C, out,
               in_kind, out_kind, reinterpret_cast<hipStream_t>(stream)};
     return run(h, r);
 }
 
-int mvx_forward_single_batch(mvx_handle *h, const double *coords, const float *radii, double radius_scalar,
+int mvx_forward_single_batch(mvx_handle *h, const double *coords, const void *radii, double radius_scalar,
                              int32_t radii_type, const int64_t *offsets, const mvx_xform *xforms, int32_t B,
-                             float *out, int32_t in_kind, int32_t out_kind, void *stream) {
+                             void *out, int32_t in_kind, int32_t out_kind, void *stream) {
     RunArgs r{MODE_SINGLE, coords, nullptr, radii, radius_scalar, radii_type, offsets, xforms, B, 1, out,
               in_kind, out_kind, reinterpret_cast<hipStream_t>(stream)};
     return run(h, r);
 }
 
-int mvx_forward_features(mvx_handle *h, const double *coords, const float *features, const float *radii,
+int mvx_forward_features(mvx_handle *h, const double *coords, const void *features, const void *radii,
                          double radius_scalar, int32_t radii_type, int64_t N, int32_t C, const mvx_xform *xform,
-                         float *out, int32_t in_kind, int32_t out_kind, void *stream) {
+                         void *out, int32_t in_kind, int32_t out_kind, void *stream) {
     const int64_t off[2] = {0, N};
     return mvx_forward_features_batch(h, coords, features, radii, radius_scalar, radii_type, off, xform, 1, C, out,
                                       in_kind, out_kind, stream);
 }
 
-int mvx_forward_types(mvx_handle *h, const double *coords, const int32_t *types, const float *radii,
+int mvx_forward_types(mvx_handle *h, const double *coords, const int32_t *types, const void *radii,
                       double radius_scalar, int32_t radii_type, int64_t N, int32_t C, const mvx_xform *xform,
-                      float *out, int32_t in_kind, int32_t out_kind, void *stream) {
+                      void *out, int32_t in_kind, int32_t out_kind, void *stream) {
     const int64_t off[2] = {0, N};
     return mvx_forward_types_batch(h, coords, types, radii, radius_scalar, radii_type, off, xform, 1, C, out,
                                    in_kind, out_kind, stream);
 }
 
-int mvx_forward_single(mvx_handle *h, const double *coords, const float *radii, double radius_scalar,
-                       int32_t radii_type, int64_t N, const mvx_xform *xform, float *out, int32_t in_kind,
+int mvx_forward_single(mvx_handle *h, const double *coords, const void *radii, double radius_scalar,
+                       int32_t radii_type, int64_t N, const mvx_xform *xform, void *out, int32_t in_kind,
                        int32_t out_kind, void *stream) {
     const int64_t off[2] = {0, N};
     return mvx_forward_single_batch(h, coords, radii, radius_scalar, radii_type, off, xform, 1, out, in_kind,

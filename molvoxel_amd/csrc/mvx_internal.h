@@ -43,14 +43,15 @@ struct Geom {
 
 struct PrepArgs {
     const double *coords;   // (total, 3)
-    const float *radii;     // per RadiiSrc
+    const void *radii;      // per RadiiSrc; float, or double when precision == 64
     const int32_t *types;   // (total,) or null
-    const float *features;  // (total, C) or null
+    const void *features;   // (total, C) or null; float / double
     int32_t mode;           // Mode: which channel weights go behind the records
     int32_t Cpad;           // channel weights per atom in wbuf (zero padded)
     const int64_t *offsets; // device, B + 1
     const mvx_xform *xforms; // device, B records, or null
-    const float *chan_aux;  // device: [0] = max channel radius (float32) for RAD_CHANNEL_FEATURES
+    const void *chan_aux;   // device: [0] = max channel radius (float / double) for RAD_CHANNEL_FEATURES
+    int32_t precision;      // 32 | 64: element type of radii, features, packed weights and the grid
     int64_t first;          // atoms [first, total) are processed by this launch (pipelined chunks)
     int64_t total;
     int32_t B;
@@ -61,7 +62,7 @@ struct PrepArgs {
     float sigma32;
     Geom g;
     AtomRec *rec;      // per-atom records
-    float *wbuf;       // packed channel weights (Cpad per atom: features zero padded / one-hot type / 1), or null when
+    void *wbuf;        // packed channel weights (Cpad per atom: features zero padded / one-hot type / 1), or null when
                        // the voxelize kernels read the caller's feature rows directly (features, C == Cpad)
     uint2 *xp;         // what the binning pass scans, 8 B per atom: {admitted x range, packed y/z ranges in slab units}
 };
@@ -77,6 +78,7 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
     int32_t dcap;          // candidate rows staged per round
     int32_t vec_store;     // D % 4 == 0 and out 16-B aligned
     int32_t store_kind;    // 0 plain, 1 nt, 2 sc1 (MVX_STORE)
+    double sigma;          // float64 grids: the Gaussian sigma as the reference holds it (python float)
 };
 
 struct VoxArgs {
@@ -86,9 +88,9 @@ struct VoxArgs {
     const uint2 *slist;    // per-slab candidate lines (xbin_kernel), SLOTS entries each
     const uint2 *slist_ext; // their extensions (entries 64..255), EXT_SLOTS entries each
     const int64_t *offsets; // device copy of the batch offsets (x-list path only)
-    const double *Tc;      // channel-wise features: per-channel d2 thresholds
+    const double *Tc;      // channel-wise features: per-channel d2 thresholds (float64 grids: the radii themselves)
     const float *kc;       //                        per-channel gaussian coefficients
-    float *out;            // (B, C, D, D, D)
+    void *out;             // (B, C, D, D, D) float, or double for float64 grids
     int *overflow;         // [0] = count (zeroed per call), [1..] ids of the slabs left to voxelize_dense_kernel
     VoxParams p;
 };
@@ -96,6 +98,7 @@ struct VoxArgs {
 // launchers (host side, mvx_kernels.hip)
 hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax,
                            double *Tc, float *kc, hipStream_t s);
+hipError_t launch_chan_aux64(const double *radii, int32_t C, double *rmax, double *Rc, hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
 hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int32_t b0, int32_t nb, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
                        uint2 *xlist, uint2 *slist, uint2 *slist_ext, int *zero_counter, hipStream_t s);
@@ -105,6 +108,8 @@ hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf
 // ct: channels per thread (1, 4, 8, 16, 32); lane_range: per-lane index-range check needed
 // voxelize molecules [a.p.b0, a.p.b0 + nb); slabs with more candidates than one line go to the overflow list
 hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
+// float64 grids: every slab of the whole batch through the general slab loop (ct <= 16; a.p.dcap must be 64)
+hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
 // process the overflow list of all launches since it was zeroed (one launch per call)
 hipError_t launch_voxelize_dense(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
 hipError_t configure_kernels(); // raises the dynamic-LDS limit of every instantiation

@@ -134,6 +134,21 @@ __global__ void chan_aux_kernel(const float *radii, int C, int density, float si
     }
 }
 
+// float64 grids: the per-channel radii themselves (the kernel divides by them) and their maximum, in float64
+__global__ void chan_aux64_kernel(const double *radii, int C, double *rmax, double *Rc) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) Rc[c] = radii[c];
+    if (threadIdx.x == 0) {
+        double m = radii[0];
+        for (int c = 1; c < C; ++c) m = radii[c] > m ? radii[c] : m;
+        rmax[0] = m;
+    }
+}
+
+hipError_t launch_chan_aux64(const double *radii, int32_t C, double *rmax, double *Rc, hipStream_t s) {
+    hipLaunchKernelGGL(chan_aux64_kernel, dim3(1), dim3(256), 0, s, radii, C, rmax, Rc);
+    return hipGetLastError();
+}
+
 hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax, double *Tc,
                            float *kc, hipStream_t s) {
     hipLaunchKernelGGL(chan_aux_kernel, dim3(1), dim3(256), 0, s, radii, C, density, sigma32, rmax, Tc, kc);
@@ -169,19 +184,22 @@ constexpr uint32_t EMPTY_ENTRY = 0x00ff00ffu; // packed y/z slab ranges: y lo = 
 // (one-hot type / 1 / zero padded features): the block copies the weights of its 256 atoms cooperatively.
 __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
     const int64_t a = A.first + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool f64 = (A.precision == 64);
     if (A.wbuf) {
         const int64_t first = A.first + (int64_t)blockIdx.x * 256;
         const int nat = (int)((A.total - first) < 256 ? (A.total - first) : 256);
-        float *wb = A.wbuf + first * A.Cpad;
         for (int i = threadIdx.x; i < nat * A.Cpad; i += 256) {
             const int al = i / A.Cpad, c = i - al * A.Cpad;
-            float f = 0.0f;
+            double f = 0.0;
             if (c < A.C) {
-                if (A.mode == MODE_FEATURES) f = A.features[(first + al) * A.C + c];
-                else if (A.mode == MODE_TYPES) f = (A.types[first + al] == c) ? 1.0f : 0.0f;
-                else f = 1.0f;
+                if (A.mode == MODE_FEATURES)
+                    f = f64 ? static_cast<const double *>(A.features)[(first + al) * A.C + c]
+                            : (double)static_cast<const float *>(A.features)[(first + al) * A.C + c];
+                else if (A.mode == MODE_TYPES) f = (A.types[first + al] == c) ? 1.0 : 0.0;
+                else f = 1.0;
             }
-            wb[i] = f;
+            if (f64) static_cast<double *>(A.wbuf)[first * A.Cpad + i] = f;
+            else static_cast<float *>(A.wbuf)[first * A.Cpad + i] = (float)f;
         }
     }
     if (a >= A.total) return;
@@ -193,7 +211,8 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
     const double ub = g.half, lb = -1 * g.half;
     float r32;   // membership radius (float32, as np.divide sees it)
     double rc;   // fp64 radius the culls use
-    float rwin;  // widest radius for the conservative index window
+    double rwin; // widest radius for the conservative index window
+    double r64 = 0.0; // float64 grids: the membership radius as np.divide sees it
     bool keep = true;
     int32_t type = 0;
     if (A.types) {
@@ -203,20 +222,36 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
     if (A.radii_src == RAD_SCALAR) {
         rc = A.radius_scalar;
         r32 = (float)A.radius_scalar;
-        rwin = r32;
+        r64 = A.radius_scalar;
+        rwin = f64 ? r64 : (double)r32;
         for (int i = 0; i < 3; ++i) keep = keep && (p[i] > lb - rc) && (p[i] < ub + rc); // numpy/voxelizer.py:487-488
     } else if (A.radii_src == RAD_CHANNEL_FEATURES) {
-        const float rmax = A.chan_aux[0];
-        r32 = rmax;
-        rwin = rmax;
-        rc = (double)rmax;
-        // np.float32 scalar: (python float -/+ float32) is evaluated in float32 (NEP 50), numpy/voxelizer.py:138
-        const double lo = (double)((float)lb - rmax), hi = (double)((float)ub + rmax);
+        double lo, hi;
+        if (f64) { // np.float64 scalar: plain float64 arithmetic
+            r64 = static_cast<const double *>(A.chan_aux)[0];
+            r32 = (float)r64;
+            rc = rwin = r64;
+            lo = lb - r64;
+            hi = ub + r64;
+        } else {
+            const float rmax = static_cast<const float *>(A.chan_aux)[0];
+            r32 = rmax;
+            rc = rwin = (double)rmax;
+            // np.float32 scalar: (python float -/+ float32) is evaluated in float32 (NEP 50), numpy/voxelizer.py:138
+            lo = (double)((float)lb - rmax);
+            hi = (double)((float)ub + rmax);
+        }
         for (int i = 0; i < 3; ++i) keep = keep && (p[i] > lo) && (p[i] < hi);
     } else {
-        r32 = (A.radii_src == RAD_ATOM) ? A.radii[a] : (keep ? A.radii[type] : 0.0f); // numpy/voxelizer.py:284-285
-        rwin = r32;
-        rc = (double)r32;
+        const int64_t ri = (A.radii_src == RAD_ATOM) ? a : (keep ? (int64_t)type : -1); // numpy/voxelizer.py:284-285
+        if (f64) {
+            r64 = ri >= 0 ? static_cast<const double *>(A.radii)[ri] : 0.0;
+            r32 = (float)r64;
+            rc = rwin = r64;
+        } else {
+            r32 = ri >= 0 ? static_cast<const float *>(A.radii)[ri] : 0.0f;
+            rc = rwin = (double)r32;
+        }
         for (int i = 0; i < 3; ++i) keep = keep && (p[i] + rc > lb) && (p[i] - rc < ub); // numpy/voxelizer.py:491-492
     }
 
@@ -224,8 +259,13 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
     R.px = p[0];
     R.py = p[1];
     R.pz = p[2];
-    R.T = d2_threshold(r32);
-    R.k = (A.density == MVX_GAUSSIAN) ? gauss_coeff(r32, A.sigma32) : 0.0f;
+    if (f64) { // the float64 kernel divides by the radius itself (T slot); non-positive radii never contribute
+        R.T = (r64 > 0.0 && r64 < INFINITY) ? r64 : -1.0;
+        R.k = 0.0f;
+    } else {
+        R.T = d2_threshold(r32);
+        R.k = (A.density == MVX_GAUSSIAN) ? gauss_coeff(r32, A.sigma32) : 0.0f;
+    }
     R.type = type;
     R.pad[0] = R.pad[1] = R.pad[2] = 0;
     keep = keep && (R.T >= 0.0);
@@ -235,7 +275,7 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
         // Voxels that can pass |p - g_i| <= r are i in [ceil((p - r - g0)/res), floor((p + r - g0)/res)]; the
         // radius is widened by 1e-6 relative (fp64 rounding of this estimate is ~1e-15) so the window is a
         // superset of the membership set; membership itself is decided per voxel with the exact threshold.
-        const double rr = (double)rwin * 1.000001 + 1e-9;
+        const double rr = rwin * 1.000001 + 1e-9;
         for (int i = 0; i < 3; ++i) {
             double flo = ceil((p[i] - rr + g.half) / g.res);
             double fhi = floor((p[i] + rr + g.half) / g.res);
@@ -531,6 +571,12 @@ size_t dense_lds_bytes(int32_t ct, int32_t NW) {
     return (size_t)8 * lcap + 16 + (tile > cand ? tile : cand);
 }
 
+// float64 kernel: rows of 16 + 2*ct words, 64 per round (p.dcap = 64), no out tile
+size_t dense64_lds_bytes(int32_t ct, int32_t NW) {
+    const int lcap = 64 * (NW < 4 ? NW : 4);
+    return (size_t)8 * lcap + 16 + (size_t)64 * (16 + 2 * ct) * 4;
+}
+
 // what a lane knows about its voxel and its workgroup's slab
 struct LaneCtx {
     double gx, gy, gz; // voxel centre: axis[i] = i*res - width/2 (numpy/voxelizer.py:41-43)
@@ -695,19 +741,110 @@ __device__ __forceinline__ LaneCtx make_lane_ctx(int lane, int wave, int x0, int
     return L;
 }
 
+// float64 grids (precision = 64): the reference then keeps distances, ratios, densities and sums in float64
+// (numpy/voxelizer.py:33-34, 544-560), so the float32 shortcuts (threshold on d2, exp2 of a product) do not apply:
+// sqrt, divide and exp are evaluated per pair exactly as written there. The record's T slot carries the radius.
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+__device__ __forceinline__ void accumulate_row64(double (&acc)[CT], const unsigned *r, const LaneCtx &L, int C,
+                                                 const double *__restrict__ Rc, double sigma) {
+    const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
+    const double2 PzR = *reinterpret_cast<const double2 *>(r + 4); // pz, radius
+    const double dx = Pxy.x - L.gx, dy = Pxy.y - L.gy, dz = PzR.x - L.gz;
+    const double d = sqrt((dx * dx + dy * dy) + dz * dz); // cdist
+    bool in_range = true;
+    if (LANE_RANGE) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(r + 8);
+        const unsigned zr = r[12];
+        in_range = (L.ix >= (int)(q.z & 0xffff)) && (L.ix <= (int)(q.z >> 16)) && (L.iy >= (int)(q.w & 0xffff)) &&
+                   (L.iy <= (int)(q.w >> 16)) && (L.iz >= (int)(zr & 0xffff)) && (L.iz <= (int)(zr >> 16));
+    }
+    const double *f = reinterpret_cast<const double *>(r + 16);
+    auto density = [&](double radius) -> double { // numpy/voxelizer.py:548-560
+        const double dr = d / radius;
+        if (!(dr <= 1.0) || !in_range) return 0.0;
+        if (!GAUSS) return 1.0;
+        const double t = dr / sigma;
+        return exp(-0.5 * (t * t));
+    };
+    if constexpr (CHANWISE) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int ch = (L.cbase + c < C) ? L.cbase + c : C - 1;
+            acc[c] = fma(density(Rc[ch]), f[c], acc[c]);
+        }
+    } else {
+        const double val = density(PzR.y);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = fma(val, f[c], acc[c]);
+    }
+}
+
+// What differs between float32 and float64 grids: accumulator type, staged row width, the per-candidate update
+// and the write-out. OpsF32 is the tuned path; OpsF64 favours exactness over speed (8-B stores straight from
+// registers, no LDS transposition).
+template <int CT_, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+struct OpsF32 {
+    static constexpr int CT = CT_;
+    typedef float2v Acc[(CT + 1) / 2];
+    static constexpr int WORDS = 1;                   // 32-bit words per channel weight
+    static constexpr int WW = CT;                     // weight words staged per row
+    static constexpr int SW = 16 + (CT < 4 ? 4 : CT); // row stride in LDS, words
+    static __device__ __forceinline__ void zero(Acc &acc) {
+#pragma unroll
+        for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
+    }
+    static __device__ __forceinline__ void accumulate(Acc &acc, const unsigned *r, const LaneCtx &L, const VoxParams &P,
+                                                      const double *__restrict__ Tc, const float *__restrict__ kc) {
+        accumulate_row<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, r, L, P.C, Tc, kc);
+    }
+    static __device__ __forceinline__ void write(const Acc &acc, bool any, unsigned *un, int tid, int lane, int wave, int NW,
+                                                 int b, const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
+        write_slab<CT>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
+                       static_cast<float *>(out), P);
+    }
+};
+
+template <int CT_, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+struct OpsF64 {
+    static constexpr int CT = CT_;
+    typedef double Acc[CT];
+    static constexpr int WORDS = 2;
+    static constexpr int WW = 2 * CT;
+    static constexpr int SW = 16 + 2 * CT;
+    static_assert(16 + WW <= 64, "a row is staged by one wave-wide load");
+    static __device__ __forceinline__ void zero(Acc &acc) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = 0.0;
+    }
+    static __device__ __forceinline__ void accumulate(Acc &acc, const unsigned *r, const LaneCtx &L, const VoxParams &P,
+                                                      const double *__restrict__ Rc, const float *__restrict__) {
+        accumulate_row64<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, r, L, P.C, Rc, P.sigma);
+    }
+    static __device__ __forceinline__ void write(const Acc &acc, bool, unsigned *, int, int, int, int, int b,
+                                                 const LaneCtx &L, int, int, int, void *out, const VoxParams &P) {
+        const int D = P.D;
+        if (L.ix >= D || L.iy >= D || L.iz >= D) return;
+        const size_t D3 = (size_t)D * D * D;
+        double *dst = static_cast<double *>(out) + ((size_t)b * P.C + L.cbase) * D3 + ((size_t)L.ix * D + L.iy) * D + L.iz;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            if (L.cbase + c < P.C) dst[(size_t)c * D3] = acc[c];
+    }
+};
+
 // One round of the line path: entries [e0, e0 + RW) of a slab line sit in the lanes of Er (lane l = entry e0 + l);
 // candidates are entries 1..n_line. Stages their rows (slot = lane index) and walks them. Ends without a barrier.
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
-__device__ __forceinline__ void line_round(float2v (&acc)[(CT + 1) / 2], const uint2 Er, int e0, int n_line, int RW,
+template <typename Ops>
+__device__ __forceinline__ void line_round(typename Ops::Acc &acc, const uint2 Er, int e0, int n_line, int RW,
                                            unsigned *un, const unsigned *__restrict__ rec, const unsigned *__restrict__ w,
                                            int64_t a0, int lane, int wave,
                                            int NW, const LaneCtx &L, const VoxParams &P, const double *__restrict__ Tc,
                                            const float *__restrict__ kc) {
-    constexpr int SW = 16 + (CT < 4 ? 4 : CT);
-    // lanes 0-15 fetch the record, lanes 16.. the CT channel weights of the chunk: one load instruction per row
-    const unsigned *src = lane < 16 ? rec + lane : w + (L.cbase + lane - 16);
-    const size_t stride = lane < 16 ? (size_t)16 : (size_t)P.w_stride;
-    const bool stager = lane < 16 + CT;
+    constexpr int SW = Ops::SW;
+    // lanes 0-15 fetch the record, lanes 16.. the channel weights of the chunk: one load instruction per row
+    const unsigned *src = lane < 16 ? rec + lane : w + (Ops::WORDS * L.cbase + lane - 16);
+    const size_t stride = lane < 16 ? (size_t)16 : (size_t)(Ops::WORDS * P.w_stride);
+    const bool stager = lane < 16 + Ops::WW;
     unsigned v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -731,7 +868,7 @@ __device__ __forceinline__ void line_round(float2v (&acc)[(CT + 1) / 2], const u
     while (mask) {
         const int sl = __builtin_ctzll(mask);
         mask &= mask - 1;
-        accumulate_row<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, un + sl * SW, L, P.C, Tc, kc);
+        Ops::accumulate(acc, un + sl * SW, L, P, Tc, kc);
     }
 }
 
@@ -739,6 +876,7 @@ template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     voxelize_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist, const double *__restrict__ Tc,
                     const float *__restrict__ kc, float *__restrict__ out, int *__restrict__ overflow, const VoxParams P) {
+    typedef OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE> Ops;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -761,9 +899,8 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
     const LaneCtx L = make_lane_ctx(lane, wave, x0, y0, z0, zc * NW, cc * CT, P);
 
-    float2v acc[(CT + 1) / 2];
-#pragma unroll
-    for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
+    typename Ops::Acc acc;
+    Ops::zero(acc);
 
     const unsigned n_hdr = (unsigned)__builtin_amdgcn_readlane((int)E.x, 0);
     const int64_t a0 = (int64_t)(unsigned)__builtin_amdgcn_readlane((int)E.y, 0);
@@ -775,20 +912,22 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
         }
         return;
     }
-    if (n_hdr > 0)
-        line_round<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, E, 0, (int)n_hdr, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
-    write_slab<CT>(acc, n_hdr > 0, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, cc * CT, x0, y0, z0, out, P);
+    if (n_hdr > 0) line_round<Ops>(acc, E, 0, (int)n_hdr, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
+    Ops::write(acc, n_hdr > 0, un, tid, lane, wave, NW, b, L, x0, y0, z0, out, P);
 }
 
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+// The general slab loop. float32: over the overflow list of the voxelize_kernel launches. float64: `overflow` is
+// null and the loop runs over all `total` (molecule, chunk, slab) ids.
+template <typename Ops>
 __global__ void __launch_bounds__(1024)
     voxelize_dense_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ xlist,
                           const uint2 *__restrict__ slist, const uint2 *__restrict__ slist_ext,
                           const int64_t *__restrict__ offsets, const double *__restrict__ Tc,
-                          const float *__restrict__ kc, float *__restrict__ out, const int *__restrict__ overflow,
-                          const VoxParams P, unsigned T) {
+                          const float *__restrict__ kc, void *__restrict__ out, const int *__restrict__ overflow,
+                          const VoxParams P, unsigned T, unsigned total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SW = 16 + (CT < 4 ? 4 : CT);
+    constexpr int SW = Ops::SW;
+    constexpr int CT = Ops::CT;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -799,11 +938,11 @@ __global__ void __launch_bounds__(1024)
     unsigned *zr_l = reinterpret_cast<unsigned *>(smem + 4 * LCAP);
     int *nlist_s = reinterpret_cast<int *>(smem + 8 * LCAP);
     unsigned *un = reinterpret_cast<unsigned *>(smem + 8 * LCAP + 16);
-    const int count = overflow[0];
+    const unsigned count = overflow ? (unsigned)overflow[0] : total;
     const int RW = 8 * NW < 64 ? 8 * NW : 64;
 
-    for (int item = blockIdx.x; item < count; item += gridDim.x) {
-        const unsigned id = (unsigned)overflow[1 + item];
+    for (unsigned item = blockIdx.x; item < count; item += gridDim.x) {
+        const unsigned id = overflow ? (unsigned)overflow[1 + item] : item;
         const unsigned z = id / T, t = id - z * T;
         int b = (int)z, cc = 0;
         if (P.ncc > 1) {
@@ -819,9 +958,8 @@ __global__ void __launch_bounds__(1024)
         const uint2 *__restrict__ ext = slist_ext + ((size_t)b * T + t) * EXT_SLOTS;
         const uint2 hdr = line[0];
         const int64_t a0 = (int64_t)hdr.y;
-        float2v acc[(CT + 1) / 2];
-#pragma unroll
-        for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
+        typename Ops::Acc acc;
+        Ops::zero(acc);
         bool any = false;
 
         if (hdr.x != LINE_OVERFLOW) {
@@ -833,16 +971,16 @@ __global__ void __launch_bounds__(1024)
                 const int e = e0 + lane;
                 uint2 Er = make_uint2(0u, EMPTY_ENTRY);
                 if (lane < RW && e <= n_line) Er = (e < SLOTS) ? line[e] : ext[e - SLOTS];
-                line_round<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, Er, e0, n_line, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
+                line_round<Ops>(acc, Er, e0, n_line, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
             }
         } else {
             // x-list path: more candidates than a line and its extension hold
             const int64_t nmol = offsets[b + 1] - offsets[b];
             const uint2 *__restrict__ xl = xlist + ((size_t)a0 + 2 * (size_t)b) * P.nsx + (size_t)sx * (size_t)(nmol + XL_HEADER);
             const int nx = (int)xl[0].x + XL_HEADER;
-            const unsigned *src = lane < 16 ? rec + lane : w + (L.cbase + lane - 16);
-            const size_t stride = lane < 16 ? (size_t)16 : (size_t)P.w_stride;
-            const bool stager = lane < 16 + CT;
+            const unsigned *src = lane < 16 ? rec + lane : w + (Ops::WORDS * L.cbase + lane - 16);
+            const size_t stride = lane < 16 ? (size_t)16 : (size_t)(Ops::WORDS * P.w_stride);
+            const bool stager = lane < 16 + Ops::WW;
             for (int base = 0; base < nx; base += LCAP) {
                 __syncthreads(); // list / candidate rows of the previous round consumed
                 if (wave == 0) { // ordered compaction of LCAP entries against the slab's y/z box
@@ -883,14 +1021,14 @@ __global__ void __launch_bounds__(1024)
                         while (mask) {
                             const int jj = jb + __builtin_ctzll(mask);
                             mask &= mask - 1;
-                            accumulate_row<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, un + jj * SW, L, P.C, Tc, kc);
+                            Ops::accumulate(acc, un + jj * SW, L, P, Tc, kc);
                         }
                     }
                 }
             }
         }
-        write_slab<CT>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, cc * CT, x0, y0, z0, out, P);
-        __syncthreads(); // tile consumed before the next slab's rows land in the union region
+        Ops::write(acc, any, un, tid, lane, wave, NW, b, L, x0, y0, z0, out, P);
+        __syncthreads(); // rows / tile consumed before the next slab's rows land in the union region
     }
 }
 
@@ -941,16 +1079,15 @@ static hipError_t raise_lds_limit(K kernel, size_t lds, size_t &raised) {
     return hipSuccess;
 }
 
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
-static hipError_t launch_dense(const VoxArgs &a, hipStream_t s) {
+template <typename Ops>
+static hipError_t launch_dense(const VoxArgs &a, const int *overflow, size_t lds, unsigned grid, unsigned total, hipStream_t s) {
     static size_t raised = 0;
     const VoxParams &p = a.p;
-    const size_t lds = dense_lds_bytes(CT, p.NW);
-    auto kern = &voxelize_dense_kernel<CT, GAUSS, CHANWISE, LANE_RANGE>;
+    auto kern = &voxelize_dense_kernel<Ops>;
     hipError_t e = raise_lds_limit(kern, lds, raised);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(512), dim3(p.NW * 64), lds, s, a.rec, a.w, a.xlist, a.slist, a.slist_ext, a.offsets, a.Tc,
-                       a.kc, a.out, a.overflow, a.p, (unsigned)(p.nzc * p.nsy * p.nsx));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(p.NW * 64), lds, s, a.rec, a.w, a.xlist, a.slist, a.slist_ext, a.offsets, a.Tc,
+                       a.kc, a.out, overflow, a.p, (unsigned)(p.nzc * p.nsy * p.nsx), total);
     return hipGetLastError();
 }
 
@@ -969,7 +1106,7 @@ struct LaunchFn {
         hipError_t e = raise_lds_limit(kern, lds, raised);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), lds, s,
-                           a.rec, a.w, a.slist, a.Tc, a.kc, a.out, a.overflow, a.p);
+                           a.rec, a.w, a.slist, a.Tc, a.kc, static_cast<float *>(a.out), a.overflow, a.p);
         return hipGetLastError();
     }
 };
@@ -979,7 +1116,25 @@ struct DenseFn {
     hipStream_t s;
     template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
     hipError_t operator()() const {
-        return launch_dense<CT, GAUSS, CHANWISE, LANE_RANGE>(a, s);
+        return launch_dense<OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE>>(a, a.overflow, dense_lds_bytes(CT, a.p.NW), 512u, 0u, s);
+    }
+};
+
+struct Dense64Fn {
+    const VoxArgs &a;
+    hipStream_t s;
+    template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
+    hipError_t operator()() const {
+        if constexpr (CT > 16) {
+            return hipErrorInvalidValue; // float64 rows are staged 16 channels at a time
+        } else {
+            const VoxParams &p = a.p;
+            const long long total = (long long)p.B * p.ncc * p.nzc * p.nsy * p.nsx;
+            if (total <= 0) return hipSuccess;
+            if (total > 0xffffffffll) return hipErrorInvalidConfiguration;
+            const unsigned grid = (unsigned)(total < 4096 ? total : 4096);
+            return launch_dense<OpsF64<CT, GAUSS, CHANWISE, LANE_RANGE>>(a, nullptr, dense64_lds_bytes(CT, p.NW), grid, (unsigned)total, s);
+        }
     }
 };
 
@@ -991,6 +1146,11 @@ hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss,
 hipError_t launch_voxelize_dense(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {
     KernelKey k{ct, gauss, chanwise, chanwise ? true : lane_range, a.p.NW <= 8 ? 512 : 1024};
     return for_kernel(k, DenseFn{a, s});
+}
+
+hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {
+    KernelKey k{ct, gauss, chanwise, chanwise ? true : lane_range, 512};
+    return for_kernel(k, Dense64Fn{a, s});
 }
 
 hipError_t configure_kernels() { return hipSuccess; }

@@ -26,6 +26,8 @@ class MvxConfig(C.Structure):
         ("blockdim", C.c_int32),
         ("density", C.c_int32),
         ("device", C.c_int32),
+        ("precision", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -54,12 +54,12 @@ class Voxelizer(BaseVoxelizer):
     ):
         super().__init__(resolution, dimension, radii_type, density_type, **kwargs)
         assert precision in [32, 64]
-        if precision != 32:
-            raise NotImplementedError("precision=64 grids are not implemented by the HIP backend yet")
         assert output in ("torch", "numpy")
         if output == "torch" and torch is None:
             raise ImportError("output='torch' needs PyTorch; use output='numpy'")
-        self.fp = np.float32
+        self.precision = precision
+        self.fp = np.float32 if precision == 32 else np.float64  # numpy/voxelizer.py:34
+        self._tfp = None if torch is None else (torch.float32 if precision == 32 else torch.float64)
         self.blockdim = blockdim if blockdim is not None else 8  # numpy/voxelizer.py:38
         self.num_blocks = -(-dimension // self.blockdim)
         self.output = output
@@ -74,6 +74,8 @@ class Voxelizer(BaseVoxelizer):
             int(self.blockdim),
             _lib.MVX_GAUSSIAN if density_type == "gaussian" else _lib.MVX_BINARY,
             self._device_index,
+            int(precision),
+            0,
         )
         _lib.check(self._lib.mvx_create(C.byref(cfg), C.byref(self._handle)))
 
@@ -118,14 +120,14 @@ class Voxelizer(BaseVoxelizer):
             shape = (batch_size,) + shape
         if self.output == "torch":
             fn = torch.zeros if init_zero else torch.empty
-            return fn(shape, dtype=torch.float32, device=self.device)
+            return fn(shape, dtype=self._tfp, device=self.device)
         return (np.zeros if init_zero else np.empty)(shape, dtype=self.fp)
 
     def asarray(self, array, obj: str):
         if obj in ("coords", "center"):
             np_dt, t_dt = np.float64, "float64"
         elif obj in ("features", "radii"):
-            np_dt, t_dt = np.float32, "float32"
+            np_dt, t_dt = (np.float32, "float32") if self.precision == 32 else (np.float64, "float64")
         elif obj == "types":
             np_dt, t_dt = np.int16, "int16"
         else:
@@ -143,7 +145,7 @@ class Voxelizer(BaseVoxelizer):
         idx = self._resolve_device(device)
         if idx != self._device_index:
             kw = {"sigma": self._sigma} if self.is_density_type_gaussian else {}
-            return type(self)(self._resolution, self._dimension, self._radii_type, self._density_type, 32,
+            return type(self)(self._resolution, self._dimension, self._radii_type, self._density_type, self.precision,
                               self.blockdim, idx, self.output, **kw)
         return self
 
@@ -169,14 +171,14 @@ class Voxelizer(BaseVoxelizer):
             ch = None
             if chan_kind == "features":
                 ch = (chan if _is_torch(chan) else torch.as_tensor(np.asarray(chan), device=self.device)).to(
-                    device=self.device, dtype=torch.float32).contiguous()
+                    device=self.device, dtype=self._tfp).contiguous()
             elif chan_kind == "types":
                 t = chan if _is_torch(chan) else torch.as_tensor(np.asarray(chan), device=self.device)
                 ch = t.to(device=self.device).to(torch.int16).to(torch.int32).contiguous()  # int16 like numpy/voxelizer.py:269
             r = None
             if not _np_isscalar(radii):
                 r = (radii if _is_torch(radii) else torch.as_tensor(np.asarray(radii), device=self.device)).to(
-                    device=self.device, dtype=torch.float32).contiguous()
+                    device=self.device, dtype=self._tfp).contiguous()
             keep += [c, ch, r]
             return c, ch, r, _lib.MVX_DEVICE, keep
         if _is_torch(coords):
@@ -185,14 +187,14 @@ class Voxelizer(BaseVoxelizer):
         ch = None
         if chan_kind == "features":
             ch = chan.detach().cpu().numpy() if _is_torch(chan) else np.asarray(chan)
-            ch = np.ascontiguousarray(ch, dtype=np.float32)
+            ch = np.ascontiguousarray(ch, dtype=self.fp)
         elif chan_kind == "types":
             t = chan.detach().cpu().numpy() if _is_torch(chan) else np.asarray(chan)
             ch = np.ascontiguousarray(t.astype(np.int16), dtype=np.int32)
         r = None
         if not _np_isscalar(radii):
             r = radii.detach().cpu().numpy() if _is_torch(radii) else np.asarray(radii)
-            r = np.ascontiguousarray(r, dtype=np.float32)
+            r = np.ascontiguousarray(r, dtype=self.fp)
         keep += [c, ch, r]
         return c, ch, r, _lib.MVX_HOST, keep
 
@@ -228,13 +230,13 @@ class Voxelizer(BaseVoxelizer):
         if out_grid is None:
             out_grid = self.get_empty_grid(shape[0])
         if _is_torch(out_grid):
-            if self._on_device(out_grid) and out_grid.is_contiguous() and out_grid.dtype == torch.float32:
+            if self._on_device(out_grid) and out_grid.is_contiguous() and out_grid.dtype == self._tfp:
                 return out_grid, _lib.MVX_DEVICE, out_grid, None
-            tmp = torch.empty(tuple(out_grid.shape), dtype=torch.float32, device=self.device)
+            tmp = torch.empty(tuple(out_grid.shape), dtype=self._tfp, device=self.device)
             return tmp, _lib.MVX_DEVICE, out_grid, "copy_torch"
-        if out_grid.flags.c_contiguous and out_grid.dtype == np.float32:
+        if out_grid.flags.c_contiguous and out_grid.dtype == self.fp:
             return out_grid, _lib.MVX_HOST, out_grid, None
-        tmp = np.empty(out_grid.shape, dtype=np.float32)
+        tmp = np.empty(out_grid.shape, dtype=self.fp)
         return tmp, _lib.MVX_HOST, out_grid, "copy_numpy"
 
     @staticmethod
@@ -301,7 +303,7 @@ class Voxelizer(BaseVoxelizer):
         if self.is_radii_type_channel_wise and r is not None and r.shape[0] < C_:
             # channel-wise radii are indexed by type only; pad so the (C,) contract of the ABI holds
             pad = C_ - r.shape[0]
-            r = torch.cat([r, r.new_ones(pad)]) if _is_torch(r) else np.concatenate([r, np.ones(pad, np.float32)])
+            r = torch.cat([r, r.new_ones(pad)]) if _is_torch(r) else np.concatenate([r, np.ones(pad, self.fp)])
         xf = self._make_xform(center, random_translation, random_rotation)
         buf, out_kind, ret, how = self._resolve_out(out_grid, (C_,))
         rs = float(radii) if _np_isscalar(radii) else 0.0

@@ -135,6 +135,36 @@ def gen_small(molvoxel):
     print(f"small_cases: {len(index)} cases")
 
 
+def gen_p64(molvoxel):
+    """precision=64 (numpy/voxelizer.py:33-34): float64 grids from the reference on small inputs."""
+    geoms = [(16, 0.5, None, 40), (12, 0.75, 5, 30), (20, 0.5, None, 60)]
+    store, index = {}, []
+    rng = np.random.default_rng(6464)
+    for gi, (D, res, bd, n_atoms) in enumerate(geoms):
+        C = 5
+        xyz, feats, types, r_atom, r_chan = small_inputs(rng, D, res, n_atoms, C)
+        store[f"g{gi}/coords"], store[f"g{gi}/features"], store[f"g{gi}/types"] = xyz, feats, types
+        store[f"g{gi}/r_atom"], store[f"g{gi}/r_chan"] = r_atom, r_chan
+        kw = {} if bd is None else {"blockdim": bd}
+        for density, sigma in (("gaussian", 0.5), ("binary", 0.5)):
+            for radii_type, rad in (("scalar", 1.0), ("atom-wise", r_atom), ("channel-wise", r_chan)):
+                v = molvoxel.create_voxelizer(res, D, radii_type, density, "numpy", sigma=sigma, precision=64, **kw)
+                for mode, chan in (("features", feats), ("types", types), ("single", None)):
+                    if mode == "single" and radii_type == "channel-wise":
+                        continue
+                    if gi == 2 and not (radii_type == "atom-wise" and mode != "single"):
+                        continue
+                    out = v.forward(xyz, None, chan, rad)
+                    assert out.dtype == np.float64
+                    cid = f"p64_g{gi}_{density}_{radii_type}_{mode}"
+                    store[f"{cid}/out"] = out
+                    index.append(dict(id=cid, geom=gi, dimension=D, resolution=res, blockdim=bd, density=density,
+                                      sigma=sigma, radii_type=radii_type, mode=mode, scalar_radius=1.0))
+    store["index"] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(GOLD, "p64_cases.npz"), **store)
+    print(f"p64_cases: {len(index)} cases")
+
+
 # ----------------------------------------------------------------------------- big cases
 def run_ref(molvoxel, wl, i=0, density=None, mode=None):
     v = molvoxel.create_voxelizer(
@@ -329,6 +359,8 @@ def main():
     only = set(filter(None, args.only.split(",")))
     if not only or "small" in only:
         gen_small(molvoxel)
+    if not only or "p64" in only:
+        gen_p64(molvoxel)
     if not only or "big" in only:
         gen_big(molvoxel, pc)
     if not only or "transform" in only:

@@ -26,8 +26,6 @@ import math
 import numpy as np
 from scipy.spatial.distance import cdist
 
-F32 = np.float32
-
 
 class GridSpec:
     """Geometry cache: axis, reference block slices, bounds."""
@@ -84,7 +82,7 @@ def _axis_tables(spec, xyz, size):
 
 
 def _density(dist32, radius, density, sigma):
-    """dist32: (V, P) float32; radius: python float or (V, 1) float32."""
+    """dist32: (V, P) in the value type; radius: python float or (V, 1) in the value type."""
     dr = np.divide(dist32, radius)
     if density == "binary":
         return np.less_equal(dr, 1.0, dr)
@@ -104,15 +102,18 @@ def voxelize(
     sigma=0.5,
     out=None,
     num_channels=None,
+    precision=32,
 ):
-    """channels: None (single), int (V,) (types) or float (V, C) (features)."""
+    """channels: None (single), int (V,) (types) or float (V, C) (features).
+    precision: 32 | 64, the reference's `self.fp` (numpy/voxelizer.py:33-34)."""
+    fp = np.float32 if precision == 32 else np.float64  # the value type everything below is cast to
     D = spec.dimension
     xyz = np.asarray(coords, dtype=np.float64)
     mode = "single" if channels is None else ("types" if np.ndim(channels) == 1 else "features")
     if not np.isscalar(radii):
-        radii = np.asarray(radii).astype(F32, copy=False)
+        radii = np.asarray(radii).astype(fp, copy=False)
     if mode == "features":
-        chan = np.asarray(channels).astype(F32, copy=False)
+        chan = np.asarray(channels).astype(fp, copy=False)
         C = chan.shape[1]
     elif mode == "types":
         chan = np.asarray(channels).astype(np.int16, copy=False)
@@ -125,7 +126,7 @@ def voxelize(
     else:
         chan, C = None, 1
     if out is None:
-        out = np.empty((C, D, D, D), dtype=F32)
+        out = np.empty((C, D, D, D), dtype=fp)
     if mode != "features":
         out.fill(0.0)
 
@@ -158,7 +159,7 @@ def voxelize(
                         view.fill(0.0)
                     continue
                 shp = view.shape[1:]
-                dist = cdist(xyz[idx], spec.points(bx, by, bz)).astype(F32)
+                dist = cdist(xyz[idx], spec.points(bx, by, bz)).astype(fp)
                 if chanwise_feat:
                     for c in range(C):
                         val = _density(dist, radii[c], density, sigma)

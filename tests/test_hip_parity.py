@@ -20,6 +20,8 @@ GAUSS_TOL = 5e-6
 Z_SMALL, IDX_SMALL = goldens.load("small_cases.npz")
 Z_BIG, IDX_BIG = goldens.load("big_cases.npz")
 Z_API, IDX_API = goldens.load("api_cases.npz")
+Z_P64, IDX_P64 = goldens.load("p64_cases.npz")
+P64_TOL = 1e-12  # float64 grids: exp / summation-order differences only (values are O(1))
 
 
 @pytest.fixture(scope="module")
@@ -156,9 +158,9 @@ def test_c_abi_direct_host_pointers(mv):
     from oracle import c_oracle
 
     lib = _lib.load()
-    assert lib.mvx_version() == 100
+    assert lib.mvx_version() == 110
     wl = W.cfg3()
-    cfg = _lib.MvxConfig(0.5, 0.5, 48, 8, _lib.MVX_BINARY, 0)
+    cfg = _lib.MvxConfig(0.5, 0.5, 48, 8, _lib.MVX_BINARY, 0, 32, 0)
     h = _lib.Handle()
     _lib.check(lib.mvx_create(C.byref(cfg), C.byref(h)))
     xyz = np.ascontiguousarray(wl.coords[0])
@@ -395,3 +397,55 @@ def test_transform_objects_on_device(mv):
             T = mv.create_random_transform(case["random_translation"], case["random_rotation"], "hip").get_transform()
             out = T(tx, center)
         assert np.array_equal(out.cpu().numpy(), z[f"{case['id']}/out"]), case["id"]
+
+
+@pytest.mark.parametrize("case", IDX_P64, ids=[c["id"] for c in IDX_P64])
+def test_precision64_golden(mv, case):
+    """precision=64 handles (numpy/voxelizer.py:33-34): float64 features / radii in, float64 grids out."""
+    coords, chan, radii = goldens.small_case_inputs(Z_P64, case)
+    ref = Z_P64[f"{case['id']}/out"]
+    extra = {} if case["blockdim"] is None else {"blockdim": case["blockdim"]}
+    v = mv.create_voxelizer(case["resolution"], case["dimension"], case["radii_type"], case["density"], "hip",
+                            sigma=case["sigma"], precision=64, output="numpy", **extra)
+    out = v.forward(coords, None, chan, radii)
+    assert out.dtype == np.float64 and out.shape == ref.shape
+    assert np.array_equal(out != 0, ref != 0), f"membership differs in {(np.not_equal(out != 0, ref != 0)).sum()} voxels"
+    if case["density"] == "binary" and case["mode"] != "features":
+        assert np.array_equal(out, ref)
+    else:
+        assert np.abs(out - ref).max() <= P64_TOL * max(1.0, float(np.abs(ref).max()))
+
+
+def test_precision64_full_size_device_tensors_and_batch(mv):
+    """cfg-2-sized float64 run (two channel chunks of 16) on torch tensors against the numpy port; batch form;
+    same out_grid object back; float32 handles are unaffected."""
+    import torch
+
+    from molvoxel_amd import workloads as W
+    from oracle import numpy_port
+
+    wl = W.cfg2(batch=3)
+    v = mv.create_voxelizer(0.5, 64, "scalar", "gaussian", "hip", precision=64)
+    assert v.get_empty_grid(2).dtype == torch.float64 and v.asarray([1.0], "radii").dtype == torch.float64
+    coords = [v.asarray(wl.coords[i], "coords") for i in range(3)]
+    feats = [v.asarray(wl.channels[i], "features") for i in range(3)]
+    grid = v.get_empty_grid(32)
+    out = v.forward_features(coords[0], None, feats[0], 1.0, out_grid=grid)
+    assert out is grid and out.dtype == torch.float64
+    spec = numpy_port.GridSpec(0.5, 64)
+    ref = numpy_port.voxelize(spec, wl.coords[0], wl.channels[0], 1.0, precision=64)
+    got = out.cpu().numpy()
+    assert np.array_equal(got != 0, ref != 0)
+    assert np.abs(got - ref).max() <= P64_TOL * max(1.0, float(np.abs(ref).max()))
+    offsets = np.arange(4, dtype=np.int64) * 4000
+    batch = v.forward_batch(torch.cat(coords), offsets, None, torch.cat(feats), 1.0)
+    assert batch.dtype == torch.float64 and torch.equal(batch[0], out)
+    for b in (1, 2):
+        assert torch.equal(batch[b], v.forward_features(coords[b], None, feats[b], 1.0))
+    # types: sums of float64 densities in atom order, exactly what the reference's loop does (:364-365)
+    vt = mv.create_voxelizer(0.5, 48, "atom-wise", "binary", "hip", precision=64, output="numpy")
+    w3 = W.cfg3()
+    rad = np.full(w3.coords[0].shape[0], 1.25)
+    ref_t = numpy_port.voxelize(numpy_port.GridSpec(0.5, 48), w3.coords[0], w3.channels[0], rad, radii_type="atom-wise",
+                                density="binary", precision=64)
+    assert np.array_equal(vt.forward_types(w3.coords[0], None, w3.channels[0], rad), ref_t)

@@ -104,9 +104,9 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/mvx.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
     loaded = _lib.load()
-    assert loaded.mvx_version() == 100
+    assert loaded.mvx_version() == 110
     # struct layouts the ABI promises
-    assert C.sizeof(_lib.MvxConfig) == 32 and C.sizeof(_lib.MvxXform) == 72
+    assert C.sizeof(_lib.MvxConfig) == 40 and C.sizeof(_lib.MvxXform) == 72
 
 
 def test_no_gpu_fails_loudly_not_silently():

@@ -77,3 +77,20 @@ def test_c_oracle_big(case):
     assert np.abs(flat[idx] - val).max() <= (0 if case["exact"] else 2e-6)
     sums = out.reshape(out.shape[0], -1).sum(axis=1, dtype=np.float64)
     assert np.allclose(sums, Z_BIG[f"{case['id']}/chan_sums"], rtol=1e-6, atol=1e-3)
+
+
+Z_P64, IDX_P64 = goldens.load("p64_cases.npz")
+
+
+@pytest.mark.parametrize("case", IDX_P64, ids=[c["id"] for c in IDX_P64])
+def test_numpy_port_precision64(case):
+    """precision=64 (numpy/voxelizer.py:33-34): float64 distances, densities and sums; same calls, same bits."""
+    coords, chan, radii = goldens.small_case_inputs(Z_P64, case)
+    ref = Z_P64[f"{case['id']}/out"]
+    spec = numpy_port.GridSpec(case["resolution"], case["dimension"], case["blockdim"])
+    out = numpy_port.voxelize(spec, coords, chan, radii, num_channels=ref.shape[0], precision=64, **_kw(case))
+    assert out.dtype == np.float64 and np.array_equal(out != 0, ref != 0)
+    if case["mode"] == "features":  # BLAS walks a strided operand in the reference and a copy here: last-bit sums
+        assert np.abs(out - ref).max() <= 1e-15 * max(1.0, float(np.abs(ref).max()))
+    else:
+        assert np.array_equal(out, ref)
