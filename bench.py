@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="cfg-2 molecules per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="cfg-2 molecules per GPU per step (8.6 GB of grids at 256)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables)")
     args = ap.parse_args()
 
