@@ -184,8 +184,11 @@ int run(mvx_handle *h, const RunArgs &r) {
         return fail(MVX_ERR_INVALID, "bad memory kind");
     const int64_t total = r.offsets[r.B];
     if (r.offsets[0] != 0) return fail(MVX_ERR_INVALID, "offsets[0] must be 0");
-    for (int b = 0; b < r.B; ++b)
+    int64_t max_atoms = 0; // of one molecule
+    for (int b = 0; b < r.B; ++b) {
         if (r.offsets[b + 1] < r.offsets[b]) return fail(MVX_ERR_INVALID, "offsets must be non-decreasing");
+        max_atoms = std::max(max_atoms, r.offsets[b + 1] - r.offsets[b]);
+    }
     if (total > 0 && !r.coords) return fail(MVX_ERR_INVALID, "coords must not be null");
     if (total > 0 && r.mode != MODE_SINGLE && !r.channels) return fail(MVX_ERR_INVALID, "channels must not be null");
     if (total >= (int64_t)1 << 31) return fail(MVX_ERR_INVALID, "too many atoms");
@@ -422,7 +425,8 @@ int run(mvx_handle *h, const RunArgs &r) {
             HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count + 1], s));
             ++h->ev_count;
         }
-        if (k == nchunk - 1) HIP_TRY(launch_voxelize_dense(va, ct, gauss, chanwise, lane_range, s));
+        // (a slab overflows at min(8 NW, 64) candidates: impossible when no molecule has that many atoms)
+        if (k == nchunk - 1 && max_atoms >= std::min(8 * NW, 64)) HIP_TRY(launch_voxelize_dense(va, ct, gauss, chanwise, lane_range, s));
     }
     if (f64) { // float64 grids: one launch of the general slab loop over the whole batch
         for (int k = 0; k < nchunk && nchunk > 1; ++k) HIP_TRY(hipStreamWaitEvent(s, h->ev_pre[k], 0));

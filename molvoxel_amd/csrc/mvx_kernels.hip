@@ -430,7 +430,8 @@ __global__ void __launch_bounds__(256)
     uint2 *ext_base = slist_ext + xslab * (size_t)nslab * EXT_SLOTS;
     const int nlds = count < XL_LDS ? count : XL_LDS;
     // each wave builds four slab lines per pass over the x-list (one LDS read and one z test per round serve all four)
-    for (int g = 4 * wave; g < nslab; g += 16) {
+    // (blockIdx.y splits the slabs of one x-slab over gridDim.y blocks when a grid has many slabs per x-slab)
+    for (int g = 4 * wave + 16 * (int)blockIdx.y; g < nslab; g += 16 * (int)gridDim.y) {
         int sy[4], zt_lo[4], zt_hi[4], n[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -480,8 +481,10 @@ __global__ void __launch_bounds__(256)
                 ln[q * SLOTS] = make_uint2(hdr, (unsigned)a0);
                 if (n[q] > LINE_CAP) any_overflow = 1;
             }
-            // the primary line leaves as one 512-B store (entries past the count are never read)
-            sl_base[(size_t)(g + q) * SLOTS + lane] = ln[q * SLOTS + lane]; // (nt: the line then misses L2 in the voxelize kernel, slower overall)
+            // the primary line leaves as one store of the used part, rounded up to 32 B (entries past the count are
+            // never interpreted): an empty slab costs 32 B, not 512. (nt stores: the line then misses L2 in the
+            // voxelize kernel, slower overall.)
+            if (lane < ((n[q] + 4) & ~3)) sl_base[(size_t)(g + q) * SLOTS + lane] = ln[q * SLOTS + lane];
         }
     }
     // the global x-list is only read by slabs on the x-list path: publish the LDS part when one exists
@@ -497,7 +500,12 @@ __global__ void __launch_bounds__(256)
 hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int32_t b0, int32_t nb, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
                        uint2 *xlist, uint2 *slist, uint2 *slist_ext, int *zero_counter, hipStream_t s) {
     if (nb <= 0) return hipSuccess;
-    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(nb * nsx)), dim3(256), 0, s, xp, offsets, b0, nsx, nsy, nzc, NW, xlist,
+    // one block builds 16 slab lines per pass; grids with more slabs per x-slab (D > 64) and few molecules get
+    // several blocks per (molecule, x-slab), each repeating the cheap pass A, until ~2048 blocks are in flight
+    const int nslab = nsy * nzc;
+    int parts = 1;
+    while (parts * 16 < nslab && (long long)nb * nsx * parts < 2048) parts *= 2;
+    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(256), 0, s, xp, offsets, b0, nsx, nsy, nzc, NW, xlist,
                        slist, slist_ext, zero_counter);
     return hipGetLastError();
 }
