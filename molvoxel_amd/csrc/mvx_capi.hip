@@ -64,7 +64,6 @@ struct mvx_handle {
     int ev_count = 0;           // timed launches recorded since the last read
     bool profiling = false;
     int force_nw = 0;
-    size_t stamp_blocks = 0;
     int max_ct = 32;
     // Pipelined pre-pass (MVX_PIPELINE=k, k > 1): the batch is cut into k chunks of molecules; prep + binning of chunk
     // j+1 run on a side stream while the caller's stream voxelizes chunk j. Off by default: on cfg-2 (64 molecules)
@@ -177,7 +176,6 @@ int run(mvx_handle *h, const RunArgs &r) {
     if (!r.offsets || !r.out) return fail(MVX_ERR_INVALID, "offsets/out must not be null");
     if (r.radii_type < MVX_RADII_SCALAR || r.radii_type > MVX_RADII_CHANNEL)
         return fail(MVX_ERR_INVALID, "bad radii_type");
-    if (r.radii_type != MVX_RADII_SCALAR && !r.radii) return fail(MVX_ERR_INVALID, "radii array required");
     if (r.radii_type == MVX_RADII_CHANNEL && r.mode == MODE_SINGLE)
         return fail(MVX_ERR_INVALID, "Channel-Wise Radii Type is not supported"); // numpy/voxelizer.py:443
     if ((r.in_kind != MVX_HOST && r.in_kind != MVX_DEVICE) || (r.out_kind != MVX_HOST && r.out_kind != MVX_DEVICE))
@@ -190,6 +188,9 @@ int run(mvx_handle *h, const RunArgs &r) {
         max_atoms = std::max(max_atoms, r.offsets[b + 1] - r.offsets[b]);
     }
     if (total > 0 && !r.coords) return fail(MVX_ERR_INVALID, "coords must not be null");
+    // (an empty molecule comes with empty, possibly null, per-atom arrays)
+    if (!r.radii && (r.radii_type == MVX_RADII_CHANNEL || (r.radii_type == MVX_RADII_ATOM && total > 0)))
+        return fail(MVX_ERR_INVALID, "radii array required");
     if (total > 0 && r.mode != MODE_SINGLE && !r.channels) return fail(MVX_ERR_INVALID, "channels must not be null");
     if (total >= (int64_t)1 << 31) return fail(MVX_ERR_INVALID, "too many atoms");
 
@@ -503,10 +504,6 @@ int mvx_create(const mvx_config *cfg, mvx_handle **out) {
     if (guard.err != hipSuccess) {
         delete h;
         return fail_hip(guard.err, "hipSetDevice");
-    }
-    if ((e = configure_kernels()) != hipSuccess) {
-        delete h;
-        return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
     *out = h;
     return MVX_OK;

@@ -112,7 +112,6 @@ hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss,
 hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
 // process the overflow list of all launches since it was zeroed (one launch per call)
 hipError_t launch_voxelize_dense(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
-hipError_t configure_kernels(); // raises the dynamic-LDS limit of every instantiation
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW);
 int32_t voxelize_dcap(int32_t ct, int32_t NW);
 

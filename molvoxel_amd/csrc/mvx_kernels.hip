@@ -1161,6 +1161,4 @@ hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chan
     return for_kernel(k, Dense64Fn{a, s});
 }
 
-hipError_t configure_kernels() { return hipSuccess; }
-
 } // namespace mvx
