@@ -9,8 +9,8 @@ Importing this package does not need a GPU; creating a voxelizer does (no CPU fa
 """
 from . import voxelizer
 from .voxelizer import create_random_transform, create_voxelizer
-from .voxelizer.base import BaseRandomTransform as RandomTransform
-from .voxelizer.base import BaseVoxelizer as Voxelizer
+from .voxelizer.contract import BaseRandomTransform as RandomTransform
+from .voxelizer.contract import BaseVoxelizer as Voxelizer
 
 __version__ = "0.1.0"
 

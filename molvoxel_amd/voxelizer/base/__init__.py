@@ -1,4 +1,4 @@
-from .transform import BaseRandomTransform, BaseT
-from .voxelizer import BaseVoxelizer
+"""Import path kept for code that reads `molvoxel.voxelizer.base`; the contract itself is in `..contract`."""
+from ..contract import BaseRandomTransform, BaseT, BaseVoxelizer
 
 __all__ = ["BaseVoxelizer", "BaseRandomTransform", "BaseT"]

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from ..base.transform import BaseRandomTransform, BaseT
+from ..contract import BaseRandomTransform, BaseT
 from ._quaternion import random_quaternion, rotate
 
 

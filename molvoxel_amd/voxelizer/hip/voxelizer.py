@@ -18,7 +18,7 @@ import ctypes as C
 
 import numpy as np
 
-from ..base import BaseVoxelizer
+from ..contract import BaseVoxelizer
 from . import _lib
 from .transform import RandomTransform, draw_forward_transform
 
@@ -67,6 +67,7 @@ class Voxelizer(BaseVoxelizer):
         self._device_index = self._resolve_device(device)
         self._handle = _lib.Handle()
         self._types_cache = None
+        self._has_torch_cuda = torch is not None and torch.cuda.is_available()  # asked on every call otherwise
         cfg = _lib.MvxConfig(
             float(resolution),
             float(getattr(self, "_sigma", 0.5)),
@@ -160,7 +161,7 @@ class Voxelizer(BaseVoxelizer):
     # ------------------------------------------------------------------------------------------
     # argument plumbing
     def _stream(self):
-        if torch is not None and torch.cuda.is_available():
+        if self._has_torch_cuda:
             return C.c_void_p(torch.cuda.current_stream(self._device_index).cuda_stream)
         return C.c_void_p(0)
 
@@ -172,7 +173,7 @@ class Voxelizer(BaseVoxelizer):
         dev = self._on_device(coords)
         keep = []
         if dev:
-            c = coords.to(torch.float64).contiguous()
+            c = coords if (coords.dtype == torch.float64 and coords.is_contiguous()) else coords.to(torch.float64).contiguous()
             ch = None
             if chan_kind == "features":
                 ch = (chan if _is_torch(chan) else torch.as_tensor(np.asarray(chan), device=self.device)).to(
