@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256)
             for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
         }
     }
-    __threadfence_block(); // the tail of a long x-list is read back by this block in pass B
+    __threadfence(); // the tail of a long x-list is read back from L2 by this block in pass B
     __syncthreads();
 
     const int nslab = nsy * nzc;
@@ -1076,20 +1076,31 @@ static hipError_t for_kernel(const KernelKey &k, Fn &&fn) {
     return hipErrorInvalidValue;
 }
 
+// Dynamic LDS above the default 64 KB limit needs an opt-in per kernel and per device (only reached with more than
+// 8 waves per workgroup, i.e. the MVX_NW experiment knob).
+constexpr int MAX_DEVICES = 64;
+struct LdsLimit {
+    size_t raised[MAX_DEVICES] = {};
+};
+
 template <typename K>
-static hipError_t raise_lds_limit(K kernel, size_t lds, size_t &raised) {
-    if (lds > 64 * 1024 && lds > raised) { // above the default dynamic-LDS limit: raise it once per instantiation
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+static hipError_t raise_lds_limit(K kernel, size_t lds, LdsLimit &state) {
+    if (lds <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if (lds > state.raised[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        raised = lds;
+        state.raised[dev] = lds;
     }
     return hipSuccess;
 }
 
 template <typename Ops>
 static hipError_t launch_dense(const VoxArgs &a, const int *overflow, size_t lds, unsigned grid, unsigned total, hipStream_t s) {
-    static size_t raised = 0;
+    static LdsLimit raised;
     const VoxParams &p = a.p;
     auto kern = &voxelize_dense_kernel<Ops>;
     hipError_t e = raise_lds_limit(kern, lds, raised);
@@ -1108,7 +1119,7 @@ struct LaunchFn {
         const VoxParams &p = a.p;
         if (nb <= 0) return hipSuccess;
         if ((long long)nb * p.ncc > 65535) return hipErrorInvalidConfiguration;
-        static size_t raised = 0;
+        static LdsLimit raised;
         const size_t lds = voxelize_lds_bytes(CT, p.NW);
         auto kern = &voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>;
         hipError_t e = raise_lds_limit(kern, lds, raised);
