@@ -411,7 +411,7 @@ int run(mvx_handle *h, const RunArgs &r) {
         pa.total = r.offsets[b1];
         HIP_TRY(launch_prep(pa, pre));
         // (the first launch also zeroes the overflow counter)
-        HIP_TRY(launch_xbin(pa.xp, d_off, b0, b1 - b0, nsx, nsy, nzc, NW, d_xlist, d_slist, d_slist_ext,
+        HIP_TRY(launch_xbin(pa.xp, d_off, b0, b1 - b0, max_atoms, nsx, nsy, nzc, NW, d_xlist, d_slist, d_slist_ext,
                             k == 0 ? va.overflow : nullptr, pre));
         if (nchunk > 1) HIP_TRY(hipEventRecord(h->ev_pre[k], pre));
     }

@@ -100,8 +100,8 @@ hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float
                            double *Tc, float *kc, hipStream_t s);
 hipError_t launch_chan_aux64(const double *radii, int32_t C, double *rmax, double *Rc, hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
-hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int32_t b0, int32_t nb, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
-                       uint2 *xlist, uint2 *slist, uint2 *slist_ext, int *zero_counter, hipStream_t s);
+hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int32_t b0, int32_t nb, int64_t max_atoms, int32_t nsx, int32_t nsy,
+                       int32_t nzc, int32_t NW, uint2 *xlist, uint2 *slist, uint2 *slist_ext, int *zero_counter, hipStream_t s);
 constexpr int SLAB_LINE_ENTRIES = 64;  // = SLOTS in mvx_kernels.hip
 constexpr int SLAB_EXT_ENTRIES = 192;  // = EXT_SLOTS
 hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf_dev, double *out, hipStream_t s);

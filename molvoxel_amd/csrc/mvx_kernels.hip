@@ -358,13 +358,18 @@ constexpr int LINE_CAP = SLOTS + EXT_SLOTS - 1; // candidates a slab can hold be
 constexpr unsigned LINE_OVERFLOW = 0xffffffffu;
 static_assert(SLOTS == SLAB_LINE_ENTRIES && EXT_SLOTS == SLAB_EXT_ENTRIES, "slab line sizes are shared with the host side");
 
-__global__ void __launch_bounds__(256)
+// THREADS = 256, or 64 (one wave per block) for batches of small molecules: the same passes with a quarter of the
+// waves, which is what 4096 blocks of a ligand batch are bound by.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
     xbin_kernel(const uint2 *__restrict__ xp, const int64_t *__restrict__ offsets, int b0, int nsx, int nsy, int nzc, int NW,
                 uint2 *__restrict__ xlist, uint2 *__restrict__ slist, uint2 *__restrict__ slist_ext, int *zero_counter) {
-    __shared__ uint2 xs[XL_LDS];
+    constexpr int XLN = THREADS == 64 ? 256 : XL_LDS; // one-wave blocks serve molecules of <= 256 atoms
+    __shared__ uint2 xs[XLN];
     __shared__ int wcnt[2][16];
     __shared__ int any_overflow;
-    __shared__ uint2 line[4][4 * SLOTS]; // the four slab lines each wave is building
+    constexpr int NWV = THREADS / 64; // waves per block
+    __shared__ uint2 line[NWV][4 * SLOTS]; // the four slab lines each wave is building
     const int b = b0 + blockIdx.x / nsx, sx = blockIdx.x % nsx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t a0 = offsets[b], a1 = offsets[b + 1];
@@ -373,7 +378,7 @@ __global__ void __launch_bounds__(256)
     if (tid == 0) any_overflow = 0;
     uint2 *dst = xlist + ((size_t)a0 + 2 * (size_t)b) * nsx + (size_t)sx * (size_t)(a1 - a0 + XL_HEADER);
     int count = 0, phase = 0;
-    // four chunks of 256 atoms per round; the next round's loads are issued before this round's barrier. Loads past
+    // four chunks of THREADS atoms per round; the next round's loads are issued before this round's barrier. Loads past
     // the molecule are clamped to its last atom and masked by value (a select between a global and a private
     // address would turn them into flat loads).
     if (a1 > a0) {
@@ -381,14 +386,14 @@ __global__ void __launch_bounds__(256)
         const int64_t alast = a1 - 1;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int64_t a = a0 + u * 256 + tid;
+            const int64_t a = a0 + u * THREADS + tid;
             cur[u] = xp[a < a1 ? a : alast];
             if (a >= a1) cur[u].x = EMPTY_RANGE;
         }
-        for (int64_t base = a0; base < a1; base += 1024, ++phase) {
+        for (int64_t base = a0; base < a1; base += 4 * THREADS, ++phase) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int64_t a = base + 1024 + u * 256 + tid;
+                const int64_t a = base + 4 * THREADS + u * THREADS + tid;
                 nxt[u] = xp[a < a1 ? a : alast];
                 if (a >= a1) nxt[u].x = EMPTY_RANGE;
             }
@@ -405,12 +410,12 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
+                for (int w = 0; w < NWV; ++w) {
                     const int c = wcnt[phase & 1][u * 4 + w];
                     if (w == wave && m[u]) {
                         const int pos = run + __builtin_amdgcn_mbcnt_hi((unsigned)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[u], 0u));
-                        const uint2 en = make_uint2((unsigned)(base + u * 256 + tid - a0), cur[u].y);
-                        if (pos < XL_LDS) xs[pos] = en;
+                        const uint2 en = make_uint2((unsigned)(base + u * THREADS + tid - a0), cur[u].y);
+                        if (pos < XLN) xs[pos] = en;
                         else dst[XL_HEADER + pos] = en; // beyond the LDS copy: straight to the global list
                     }
                     run += c;
@@ -430,10 +435,10 @@ __global__ void __launch_bounds__(256)
     const size_t xslab = (size_t)b * nsx + sx;
     uint2 *sl_base = slist + xslab * (size_t)nslab * SLOTS;
     uint2 *ext_base = slist_ext + xslab * (size_t)nslab * EXT_SLOTS;
-    const int nlds = count < XL_LDS ? count : XL_LDS;
+    const int nlds = count < XLN ? count : XLN;
     // each wave builds four slab lines per pass over the x-list (one LDS read and one z test per round serve all four)
     // (blockIdx.y splits the slabs of one x-slab over gridDim.y blocks when a grid has many slabs per x-slab)
-    for (int g = 4 * wave + 16 * (int)blockIdx.y; g < nslab; g += 16 * (int)gridDim.y) {
+    for (int g = 4 * wave + 4 * NWV * (int)blockIdx.y; g < nslab; g += 4 * NWV * (int)gridDim.y) {
         int sy[4], zt_lo[4], zt_hi[4], n[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -465,7 +470,7 @@ __global__ void __launch_bounds__(256)
             const int i = i0 + lane;
             take(i < nlds ? xs[i] : make_uint2(0u, EMPTY_ENTRY));
         }
-        for (int i0 = XL_LDS; i0 < count; i0 += 64) { // beyond the LDS copy: this block's own stores, read back
+        for (int i0 = XLN; i0 < count; i0 += 64) { // beyond the LDS copy: this block's own stores, read back
             const int i = i0 + lane;
             uint2 en = make_uint2(0u, EMPTY_ENTRY);
             if (i < count) {
@@ -494,21 +499,28 @@ __global__ void __launch_bounds__(256)
     if (any_overflow) {
         if (tid == 0) dst[0] = make_uint2((unsigned)count, EMPTY_ENTRY);
         if (tid == 1) dst[1] = make_uint2((unsigned)a0, EMPTY_ENTRY);
-        const int nl = count < XL_LDS ? count : XL_LDS;
-        for (int i = tid; i < nl; i += 256) dst[XL_HEADER + i] = xs[i];
+        const int nl = count < XLN ? count : XLN;
+        for (int i = tid; i < nl; i += THREADS) dst[XL_HEADER + i] = xs[i];
     }
 }
 
-hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int32_t b0, int32_t nb, int32_t nsx, int32_t nsy, int32_t nzc, int32_t NW,
-                       uint2 *xlist, uint2 *slist, uint2 *slist_ext, int *zero_counter, hipStream_t s) {
+hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int32_t b0, int32_t nb, int64_t max_atoms, int32_t nsx, int32_t nsy,
+                       int32_t nzc, int32_t NW, uint2 *xlist, uint2 *slist, uint2 *slist_ext, int *zero_counter, hipStream_t s) {
     if (nb <= 0) return hipSuccess;
+    const int nslab = nsy * nzc;
+    if (max_atoms <= 256) { // small molecules (one round of pass A for a single wave): one-wave blocks
+        int parts = 1;
+        while (parts * 4 < nslab && parts < 4 && (long long)nb * nsx * parts < 8192) parts *= 2;
+        hipLaunchKernelGGL(xbin_kernel<64>, dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(64), 0, s, xp, offsets, b0, nsx, nsy,
+                           nzc, NW, xlist, slist, slist_ext, zero_counter);
+        return hipGetLastError();
+    }
     // one block builds 16 slab lines per pass; grids with more slabs per x-slab (D > 64) and few molecules get
     // several blocks per (molecule, x-slab), each repeating the cheap pass A, until ~2048 blocks are in flight
-    const int nslab = nsy * nzc;
     int parts = 1;
     while (parts * 16 < nslab && (long long)nb * nsx * parts < 2048) parts *= 2;
-    hipLaunchKernelGGL(xbin_kernel, dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(256), 0, s, xp, offsets, b0, nsx, nsy, nzc, NW, xlist,
-                       slist, slist_ext, zero_counter);
+    hipLaunchKernelGGL(xbin_kernel<256>, dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(256), 0, s, xp, offsets, b0, nsx, nsy,
+                       nzc, NW, xlist, slist, slist_ext, zero_counter);
     return hipGetLastError();
 }
 
