@@ -366,9 +366,9 @@ __global__ void __launch_bounds__(THREADS)
                 uint2 *__restrict__ xlist, uint2 *__restrict__ slist, uint2 *__restrict__ slist_ext, int *zero_counter) {
     constexpr int XLN = THREADS == 64 ? 256 : XL_LDS; // one-wave blocks serve molecules of <= 256 atoms
     __shared__ uint2 xs[XLN];
-    __shared__ int wcnt[2][16];
-    __shared__ int any_overflow;
     constexpr int NWV = THREADS / 64; // waves per block
+    __shared__ int wcnt[2][4 * NWV];
+    __shared__ int any_overflow;
     __shared__ uint2 line[NWV][4 * SLOTS]; // the four slab lines each wave is building
     const int b = b0 + blockIdx.x / nsx, sx = blockIdx.x % nsx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(THREADS)
             for (int u = 0; u < 4; ++u) {
                 m[u] = ((int)(cur[u].x & 0xffff) <= x0 + SUBX - 1) && ((int)(cur[u].x >> 16) >= x0);
                 mask[u] = __ballot(m[u]);
-                if (lane == 0) wcnt[phase & 1][u * 4 + wave] = __popcll(mask[u]);
+                if (lane == 0) wcnt[phase & 1][u * NWV + wave] = __popcll(mask[u]);
             }
             __syncthreads();
             int run = count;
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(THREADS)
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
                 for (int w = 0; w < NWV; ++w) {
-                    const int c = wcnt[phase & 1][u * 4 + w];
+                    const int c = wcnt[phase & 1][u * NWV + w];
                     if (w == wave && m[u]) {
                         const int pos = run + __builtin_amdgcn_mbcnt_hi((unsigned)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[u], 0u));
                         const uint2 en = make_uint2((unsigned)(base + u * THREADS + tid - a0), cur[u].y);
