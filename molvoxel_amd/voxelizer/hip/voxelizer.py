@@ -158,6 +158,9 @@ class Voxelizer(BaseVoxelizer):
     def cuda(self):
         return self
 
+    def cpu(self):
+        raise NotImplementedError("the HIP backend has no CPU path; use the upstream numpy backend on the host")
+
     # ------------------------------------------------------------------------------------------
     # argument plumbing
     def _stream(self):
