@@ -72,6 +72,7 @@ struct mvx_handle {
     int pipeline = 1;
     std::vector<char> meta_last; // host copy of the offsets the device meta buffer holds
     bool meta_valid = false;
+    hipStream_t meta_stream = nullptr;
     hipStream_t side = nullptr;
     hipEvent_t ev_in = nullptr;
     std::vector<hipEvent_t> ev_pre;
@@ -226,7 +227,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     // offsets (+ transforms) go to the device only when they differ from what the last call left there
     // (same-shaped batches, the common case in a training loop, skip a 5 us copy kernel)
     const size_t meta_used = (size_t)(r.B + 1) * sizeof(int64_t);
-    const bool meta_same = !r.xforms && h->meta_valid && h->meta_last.size() == meta_used &&
+    const bool meta_same = !r.xforms && h->meta_valid && h->meta_stream == s && h->meta_last.size() == meta_used &&
                            std::memcmp(h->meta_last.data(), r.offsets, meta_used) == 0;
     if (!meta_same) {
         std::memcpy(pin, r.offsets, meta_used);
@@ -234,6 +235,7 @@ int run(mvx_handle *h, const RunArgs &r) {
         HIP_TRY(hipMemcpyAsync(h->meta.p, pin, off_bytes + xf_bytes, hipMemcpyHostToDevice, s));
         h->meta_last.assign(reinterpret_cast<const char *>(r.offsets), reinterpret_cast<const char *>(r.offsets) + meta_used);
         h->meta_valid = !r.xforms;
+        h->meta_stream = s; // the copy is ordered on this stream only
     }
     const int64_t *d_off = reinterpret_cast<const int64_t *>(h->meta.p);
     const mvx_xform *d_xf = r.xforms ? reinterpret_cast<const mvx_xform *>((char *)h->meta.p + off_bytes) : nullptr;
