@@ -449,3 +449,37 @@ def test_precision64_full_size_device_tensors_and_batch(mv):
     ref_t = numpy_port.voxelize(numpy_port.GridSpec(0.5, 48), w3.coords[0], w3.channels[0], rad, radii_type="atom-wise",
                                 density="binary", precision=64)
     assert np.array_equal(vt.forward_types(w3.coords[0], None, w3.channels[0], rad), ref_t)
+
+
+def test_offsets_cache_across_calls_and_streams(mv):
+    """The device copy of the batch offsets is reused while they do not change (and only on the stream that uploaded
+    them): same offsets, different offsets of the same length, a transform in between, another stream."""
+    import torch
+
+    rng = np.random.default_rng(31)
+    D = 24
+    W_ = 0.5 * (D - 1)
+    v = mv.create_voxelizer(0.5, D, "scalar", "binary", "hip")
+
+    def batch(sizes):
+        coords = rng.uniform(-W_ / 2, W_ / 2, (sum(sizes), 3))
+        types = rng.integers(0, 3, sum(sizes))
+        offsets = np.cumsum([0] + sizes)
+        out = v.forward_batch(v.asarray(coords, "coords"), offsets, None, v.asarray(types, "types"), 1.0, num_channels=3)
+        for b in range(len(sizes)):
+            lo, hi = offsets[b], offsets[b + 1]
+            one = v.forward_types(v.asarray(coords[lo:hi], "coords"), None, v.asarray(types[lo:hi], "types"), 1.0,
+                                  out_grid=v.get_empty_grid(3)) if hi > lo else torch.zeros_like(out[b])
+            assert torch.equal(out[b], one), (sizes, b)
+
+    batch([10, 20, 30])
+    batch([10, 20, 30])  # cached offsets
+    batch([30, 20, 10])  # same length, different content
+    v.transform_class(0.5, True).forward(v.asarray(rng.uniform(-1, 1, (5, 3)), "coords"), None)  # other user of the handle
+    batch([30, 20, 10])
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        batch([30, 20, 10])  # same offsets, other stream: uploaded again
+        batch([5, 5, 50])
+    torch.cuda.synchronize()
