@@ -170,7 +170,8 @@ struct RunArgs {
     hipStream_t stream;
 };
 
-int run(mvx_handle *h, const RunArgs &r) {
+// ---- 1. what the library checks itself (shapes are the Python layer's job) -----------------------------------------
+int validate(const mvx_handle *h, const RunArgs &r, int64_t &total, int64_t &max_atoms) {
     if (!h) return fail(MVX_ERR_INVALID, "null handle");
     if (r.B < 0 || r.C <= 0) return fail(MVX_ERR_INVALID, "B must be >= 0 and C > 0");
     if (r.B == 0) return MVX_OK;
@@ -181,9 +182,9 @@ int run(mvx_handle *h, const RunArgs &r) {
         return fail(MVX_ERR_INVALID, "Channel-Wise Radii Type is not supported"); // numpy/voxelizer.py:443
     if ((r.in_kind != MVX_HOST && r.in_kind != MVX_DEVICE) || (r.out_kind != MVX_HOST && r.out_kind != MVX_DEVICE))
         return fail(MVX_ERR_INVALID, "bad memory kind");
-    const int64_t total = r.offsets[r.B];
     if (r.offsets[0] != 0) return fail(MVX_ERR_INVALID, "offsets[0] must be 0");
-    int64_t max_atoms = 0; // of one molecule
+    total = r.offsets[r.B];
+    max_atoms = 0; // of one molecule
     for (int b = 0; b < r.B; ++b) {
         if (r.offsets[b + 1] < r.offsets[b]) return fail(MVX_ERR_INVALID, "offsets must be non-decreasing");
         max_atoms = std::max(max_atoms, r.offsets[b + 1] - r.offsets[b]);
@@ -194,36 +195,41 @@ int run(mvx_handle *h, const RunArgs &r) {
         return fail(MVX_ERR_INVALID, "radii array required");
     if (total > 0 && r.mode != MODE_SINGLE && !r.channels) return fail(MVX_ERR_INVALID, "channels must not be null");
     if (total >= (int64_t)1 << 31) return fail(MVX_ERR_INVALID, "too many atoms");
+    if (r.out_kind == MVX_DEVICE && (reinterpret_cast<uintptr_t>(r.out) & 15u) != 0)
+        return fail(MVX_ERR_INVALID, "device out pointer must be 16-byte aligned");
+    return MVX_OK;
+}
 
-    DeviceGuard guard(h->device);
-    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
-    hipStream_t s = r.stream;
-    const Geom &g = h->g;
-    const int D = g.D;
-    const size_t D3 = (size_t)D * D * D;
-    const bool f64 = (h->cfg.precision == 64);
-    const size_t esz = f64 ? sizeof(double) : sizeof(float); // element size of features, radii and the grid
-    const size_t out_bytes = (size_t)r.B * r.C * D3 * esz;
+// ---- 2. inputs and metadata on the device ---------------------------------------------------------------------------
+struct DeviceInputs {
+    const int64_t *offsets = nullptr;
+    const mvx_xform *xforms = nullptr;
+    const double *coords = nullptr;
+    const void *channels = nullptr;
+    const void *radii = nullptr;
+    PinnedSlot *slot = nullptr; // holds the host copies until `done` fires
+};
 
-    // ---- host-side metadata (+ host-resident inputs) -> one pinned slot -> device ----------------
+// Host-resident arrays go through one pinned slot (a single memcpy each, then async H2D on the caller's stream);
+// device-resident arrays are used where they are. Offsets and transforms always come from the host.
+int stage_inputs(mvx_handle *h, const RunArgs &r, int64_t total, size_t esz, hipStream_t s, DeviceInputs &in) {
     const size_t off_bytes = align_up((size_t)(r.B + 1) * sizeof(int64_t), 16);
     const size_t xf_bytes = r.xforms ? align_up((size_t)r.B * sizeof(mvx_xform), 16) : 0;
     const bool host_in = (r.in_kind == MVX_HOST);
     const size_t chan_elem = (r.mode == MODE_FEATURES) ? (size_t)r.C * esz : (r.mode == MODE_TYPES ? sizeof(int32_t) : 0);
-    const size_t co_bytes = host_in ? align_up((size_t)total * 3 * sizeof(double), 16) : 0;
-    const size_t ch_bytes = host_in ? align_up((size_t)total * chan_elem, 16) : 0;
     size_t rad_count = 0;
     if (r.radii_type == MVX_RADII_ATOM) rad_count = (size_t)total;
     else if (r.radii_type == MVX_RADII_CHANNEL) rad_count = (size_t)r.C;
+    const size_t co_bytes = host_in ? align_up((size_t)total * 3 * sizeof(double), 16) : 0;
+    const size_t ch_bytes = host_in ? align_up((size_t)total * chan_elem, 16) : 0;
     const size_t ra_bytes = host_in ? align_up(rad_count * esz, 16) : 0;
 
-    PinnedSlot *slot = nullptr;
-    int rc = acquire_slot(h, off_bytes + xf_bytes + co_bytes + ch_bytes + ra_bytes, &slot);
+    int rc = acquire_slot(h, off_bytes + xf_bytes + co_bytes + ch_bytes + ra_bytes, &in.slot);
     if (rc) return rc;
+    char *pin = in.slot->p;
     const void *meta_before = h->meta.p;
     if ((rc = ensure(h->meta, off_bytes + xf_bytes))) return rc;
     if (h->meta.p != meta_before) h->meta_valid = false;
-    char *pin = slot->p;
     // offsets (+ transforms) go to the device only when they differ from what the last call left there
     // (same-shaped batches, the common case in a training loop, skip a 5 us copy kernel)
     const size_t meta_used = (size_t)(r.B + 1) * sizeof(int64_t);
@@ -237,41 +243,87 @@ int run(mvx_handle *h, const RunArgs &r) {
         h->meta_valid = !r.xforms;
         h->meta_stream = s; // the copy is ordered on this stream only
     }
-    const int64_t *d_off = reinterpret_cast<const int64_t *>(h->meta.p);
-    const mvx_xform *d_xf = r.xforms ? reinterpret_cast<const mvx_xform *>((char *)h->meta.p + off_bytes) : nullptr;
+    in.offsets = reinterpret_cast<const int64_t *>(h->meta.p);
+    in.xforms = r.xforms ? reinterpret_cast<const mvx_xform *>((char *)h->meta.p + off_bytes) : nullptr;
+    in.coords = r.coords;
+    in.channels = r.channels;
+    in.radii = r.radii;
+    if (!host_in) return MVX_OK;
 
-    const double *d_coords = r.coords;
-    const void *d_chan = r.channels;
-    const void *d_radii = r.radii;
-    if (host_in && total > 0) {
-        char *q = pin + off_bytes + xf_bytes;
-        if ((rc = ensure(h->in_coords, co_bytes))) return rc;
-        std::memcpy(q, r.coords, (size_t)total * 3 * sizeof(double));
-        HIP_TRY(hipMemcpyAsync(h->in_coords.p, q, co_bytes, hipMemcpyHostToDevice, s));
-        d_coords = reinterpret_cast<const double *>(h->in_coords.p);
-        q += co_bytes;
-        if (ch_bytes) {
-            if ((rc = ensure(h->in_chan, ch_bytes))) return rc;
-            std::memcpy(q, r.channels, (size_t)total * chan_elem);
-            HIP_TRY(hipMemcpyAsync(h->in_chan.p, q, ch_bytes, hipMemcpyHostToDevice, s));
-            d_chan = h->in_chan.p;
-            q += ch_bytes;
-        }
-    }
-    if (host_in && rad_count > 0) {
-        char *q = pin + off_bytes + xf_bytes + co_bytes + ch_bytes;
-        if ((rc = ensure(h->in_radii, ra_bytes))) return rc;
-        std::memcpy(q, r.radii, rad_count * esz);
-        HIP_TRY(hipMemcpyAsync(h->in_radii.p, q, ra_bytes, hipMemcpyHostToDevice, s));
-        d_radii = h->in_radii.p;
-    }
+    auto upload = [&](DevBuf &dst, const void *src, size_t used, size_t padded, char *staging, const void *&dev) -> int {
+        if (used == 0) return MVX_OK;
+        if (int e = ensure(dst, padded)) return e;
+        std::memcpy(staging, src, used);
+        HIP_TRY(hipMemcpyAsync(dst.p, staging, padded, hipMemcpyHostToDevice, s));
+        dev = dst.p;
+        return MVX_OK;
+    };
+    char *q = pin + off_bytes + xf_bytes;
+    const void *dev_coords = in.coords;
+    if ((rc = upload(h->in_coords, r.coords, (size_t)total * 3 * sizeof(double), co_bytes, q, dev_coords))) return rc;
+    in.coords = static_cast<const double *>(dev_coords);
+    if ((rc = upload(h->in_chan, r.channels, (size_t)total * chan_elem, ch_bytes, q + co_bytes, in.channels))) return rc;
+    if ((rc = upload(h->in_radii, r.radii, rad_count * esz, ra_bytes, q + co_bytes + ch_bytes, in.radii))) return rc;
+    return MVX_OK;
+}
 
+// ---- 3. slab decomposition of the grid ------------------------------------------------------------------------------
+// slab = SUBX x SUBY x (SUBZ*NW) voxels, NW waves side by side along z. Whole rows (NW = row length in sub-tiles) up to
+// 8 waves; longer rows are cut into chunks of 8 sub-tiles (256-B runs).
+struct SlabPlan {
+    int nsx, nsy, nzc, NW;
+    size_t per_molecule() const { return (size_t)nsx * nsy * nzc; }
+};
+
+SlabPlan plan_slabs(const mvx_handle *h) {
+    const int D = h->g.D;
+    SlabPlan sp;
+    sp.nsx = (D + SUBX - 1) / SUBX;
+    sp.nsy = (D + SUBY - 1) / SUBY;
+    const int nsz = (D + SUBZ - 1) / SUBZ;
+    sp.NW = nsz <= 8 ? nsz : 8;
+    if (h->force_nw > 0 && h->force_nw <= 16) sp.NW = std::min(h->force_nw, nsz); // MVX_NW experiment knob
+    sp.nzc = (nsz + sp.NW - 1) / sp.NW;
+    return sp;
+}
+
+inline uint32_t umulhi_inverse(int d) { // n / d == __umulhi(n, inv) for the slab ids used (n * d < 2^32); d == 1 is special-cased by the kernel
+    return d == 1 ? 0xffffffffu : (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d);
+}
+
+// ---- 4. launches bracketed by profiling events when mvx_set_profiling is on ----------------------------------------
+template <typename Launch>
+int timed_launch(mvx_handle *h, hipStream_t s, Launch &&launch) {
+    const bool timed = h->profiling && h->ev_count < MVX_PROFILE_RING;
+    if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count], s));
+    HIP_TRY(launch());
+    if (timed) {
+        HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count + 1], s));
+        ++h->ev_count;
+    }
+    return MVX_OK;
+}
+
+int run(mvx_handle *h, const RunArgs &r) {
+    int64_t total = 0, max_atoms = 0;
+    int rc = validate(h, r, total, max_atoms);
+    if (rc || r.B == 0) return rc;
+
+    DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
+    hipStream_t s = r.stream;
+    const Geom &g = h->g;
+    const int D = g.D;
+    const bool f64 = (h->cfg.precision == 64);
+    const size_t esz = f64 ? sizeof(double) : sizeof(float); // element size of features, radii and the grid
+    const size_t out_bytes = (size_t)r.B * r.C * D * D * D * esz;
+
+    DeviceInputs in;
+    if ((rc = stage_inputs(h, r, total, esz, s, in))) return rc;
     void *d_out = r.out;
     if (r.out_kind == MVX_HOST) {
         if ((rc = ensure(h->out_stage, out_bytes))) return rc;
         d_out = h->out_stage.p;
-    } else if ((reinterpret_cast<uintptr_t>(r.out) & 15u) != 0) {
-        return fail(MVX_ERR_INVALID, "device out pointer must be 16-byte aligned");
     }
 
     // ---- workspace --------------------------------------------------------------------------------
@@ -282,9 +334,19 @@ int run(mvx_handle *h, const RunArgs &r) {
     const int Cpad = (ncc > 1) ? ncc * ct : (ct < 4 ? 4 : ct); // channel weights per atom, zero padded
     // feature rows that already are Cpad wide are read in place; anything else (one-hot types, 1, padding) is packed
     const bool direct_w = (r.mode == MODE_FEATURES && r.C == Cpad);
+    const SlabPlan sp = plan_slabs(h);
+    const size_t nslabs = (size_t)r.B * sp.per_molecule();
+    if (nslabs * (size_t)ncc + 1 > (size_t)0x7fffffff) return fail(MVX_ERR_INVALID, "batch too large for one call");
     if ((rc = ensure(h->rec, n_alloc * sizeof(AtomRec)))) return rc;
     if (!direct_w && (rc = ensure(h->wbuf, n_alloc * (size_t)Cpad * esz))) return rc;
     if ((rc = ensure(h->xp, n_alloc * sizeof(uint2)))) return rc;
+    // x-lists: packed regions, (sum(N) + 2*B) * nsx entries; slab lines: primary + extension entries per slab
+    if ((rc = ensure(h->xlist, ((size_t)total + 2 * (size_t)r.B) * sp.nsx * sizeof(uint2)))) return rc;
+    if ((rc = ensure(h->slist, nslabs * (SLAB_LINE_ENTRIES + SLAB_EXT_ENTRIES) * sizeof(uint2)))) return rc;
+    if ((rc = ensure(h->overflow, (nslabs * (size_t)ncc + 1) * sizeof(int)))) return rc;
+    uint2 *d_xlist = reinterpret_cast<uint2 *>(h->xlist.p);
+    uint2 *d_slist = reinterpret_cast<uint2 *>(h->slist.p);
+    uint2 *d_slist_ext = d_slist + nslabs * SLAB_LINE_ENTRIES; // extension lines live behind the primary lines
 
     const bool gauss = (h->cfg.density == MVX_GAUSSIAN);
     const bool chanwise = (r.radii_type == MVX_RADII_CHANNEL && r.mode == MODE_FEATURES);
@@ -298,22 +360,22 @@ int run(mvx_handle *h, const RunArgs &r) {
         d_Tc = reinterpret_cast<double *>((char *)h->aux.p + tc_off);
         d_kc = reinterpret_cast<float *>((char *)h->aux.p + kc_off);
         if (f64)
-            HIP_TRY(launch_chan_aux64(static_cast<const double *>(d_radii), r.C, static_cast<double *>(d_rmax), d_Tc, s));
+            HIP_TRY(launch_chan_aux64(static_cast<const double *>(in.radii), r.C, static_cast<double *>(d_rmax), d_Tc, s));
         else
-            HIP_TRY(launch_chan_aux(static_cast<const float *>(d_radii), r.C, h->cfg.density, h->sigma32,
+            HIP_TRY(launch_chan_aux(static_cast<const float *>(in.radii), r.C, h->cfg.density, h->sigma32,
                                     static_cast<float *>(d_rmax), d_Tc, d_kc, s));
     }
 
-    // ---- prep -------------------------------------------------------------------------------------
+    // ---- kernel arguments -------------------------------------------------------------------------
     PrepArgs pa;
-    pa.coords = d_coords;
-    pa.radii = d_radii;
-    pa.types = (r.mode == MODE_TYPES) ? reinterpret_cast<const int32_t *>(d_chan) : nullptr;
-    pa.features = (r.mode == MODE_FEATURES) ? d_chan : nullptr;
+    pa.coords = in.coords;
+    pa.radii = in.radii;
+    pa.types = (r.mode == MODE_TYPES) ? reinterpret_cast<const int32_t *>(in.channels) : nullptr;
+    pa.features = (r.mode == MODE_FEATURES) ? in.channels : nullptr;
     pa.mode = r.mode;
     pa.Cpad = Cpad;
-    pa.offsets = d_off;
-    pa.xforms = d_xf;
+    pa.offsets = in.offsets;
+    pa.xforms = in.xforms;
     pa.chan_aux = d_rmax;
     pa.precision = f64 ? 64 : 32;
     pa.first = 0;
@@ -331,69 +393,46 @@ int run(mvx_handle *h, const RunArgs &r) {
     pa.wbuf = direct_w ? nullptr : h->wbuf.p;
     pa.xp = reinterpret_cast<uint2 *>(h->xp.p);
 
-    // ---- voxelize ---------------------------------------------------------------------------------
     VoxArgs va;
     va.rec = reinterpret_cast<const unsigned *>(h->rec.p);
-    va.w = direct_w ? reinterpret_cast<const unsigned *>(d_chan) : reinterpret_cast<const unsigned *>(h->wbuf.p);
-    va.p.w_stride = Cpad;
+    va.w = reinterpret_cast<const unsigned *>(direct_w ? in.channels : h->wbuf.p);
+    va.xlist = d_xlist;
+    va.slist = d_slist;
+    va.slist_ext = d_slist_ext;
+    va.offsets = in.offsets;
     va.Tc = d_Tc;
     va.kc = d_kc;
     va.out = d_out;
+    va.overflow = reinterpret_cast<int *>(h->overflow.p);
     va.p.res = g.res;
     va.p.half = g.half;
     va.p.D = D;
     va.p.C = r.C;
     va.p.B = r.B;
-    // slab = SUBX x SUBY x (SUBZ*NW) voxels, NW waves side by side along z. Prefer whole rows (NW = row length in
-    // sub-tiles) up to 8 waves; longer rows are cut into chunks of 8 sub-tiles (256-B runs).
-    const int nsx = (D + SUBX - 1) / SUBX, nsy = (D + SUBY - 1) / SUBY, nsz = (D + SUBZ - 1) / SUBZ;
-    int NW, nzc;
-    if (nsz <= 8) {
-        NW = nsz;
-        nzc = 1;
-    } else {
-        NW = 8;
-        nzc = (nsz + 7) / 8;
-    }
-    if (h->force_nw > 0 && h->force_nw <= 16) {
-        NW = std::min(h->force_nw, nsz);
-        nzc = (nsz + NW - 1) / NW;
-    }
-    va.p.nsx = nsx;
-    va.p.nsy = nsy;
-    va.p.nsy_inv = (uint32_t)((0x100000000ull + (uint64_t)nsy - 1) / (uint64_t)nsy);
-    va.p.nzc = nzc;
-    va.p.nzc_inv = (nzc == 1) ? 0xffffffffu : (uint32_t)((0x100000000ull + (uint64_t)nzc - 1) / (uint64_t)nzc);
-    va.p.NW = NW;
-    // x-slab binning (ordered lists per (molecule, x-slab), fixed-stride regions)
-    // x-lists: packed regions, (sum(N) + 2*B) * nsx entries; slab lines: SLAB_LINE_ENTRIES entries per slab
-    if ((rc = ensure(h->xlist, ((size_t)total + 2 * (size_t)r.B) * nsx * sizeof(uint2)))) return rc;
-    const size_t nslabs = (size_t)r.B * nsx * nsy * nzc;
-    if ((rc = ensure(h->slist, nslabs * (SLAB_LINE_ENTRIES + SLAB_EXT_ENTRIES) * sizeof(uint2)))) return rc;
-    uint2 *d_slist = reinterpret_cast<uint2 *>(h->slist.p);
-    uint2 *d_slist_ext = d_slist + nslabs * SLAB_LINE_ENTRIES; // extension lines live behind the primary lines
-    va.slist = d_slist;
-    va.slist_ext = d_slist_ext;
-    if (nslabs * (size_t)ncc + 1 > (size_t)0x7fffffff) return fail(MVX_ERR_INVALID, "batch too large for one call");
-    if ((rc = ensure(h->overflow, (nslabs * (size_t)ncc + 1) * sizeof(int)))) return rc;
-    va.overflow = reinterpret_cast<int *>(h->overflow.p);
-    va.offsets = d_off;
-    va.xlist = reinterpret_cast<const uint2 *>(h->xlist.p);
+    va.p.nsx = sp.nsx;
+    va.p.nsy = sp.nsy;
+    va.p.nzc = sp.nzc;
     va.p.ncc = ncc;
-    va.p.dcap = f64 ? 64 : voxelize_dcap(ct, NW);
-    va.p.sigma = h->cfg.sigma;
+    va.p.nsy_inv = umulhi_inverse(sp.nsy);
+    va.p.nzc_inv = umulhi_inverse(sp.nzc);
+    va.p.b0 = 0;
+    va.p.NW = sp.NW;
+    va.p.w_stride = Cpad;
+    va.p.dcap = f64 ? 64 : voxelize_dcap(ct, sp.NW);
     va.p.vec_store = (D % 4 == 0) ? 1 : 0;
     va.p.store_kind = h->store_kind;
+    va.p.sigma = h->cfg.sigma;
     // a sub-tile lies inside one reference block when its edges divide blockdim (or there is a single block):
     // the block cull is then wave-uniform and already folded into the candidate ranges.
     const bool lane_range = !(g.nb == 1 || (g.bd % SUBX == 0 && g.bd % SUBY == 0 && g.bd % SUBZ == 0));
 
-    // ---- chunk plan: pre-pass (prep + binning) on the side stream, one chunk ahead of the voxelize launches ----
-    const int max_mol = 65535 / ncc; // gridDim.y limit per launch
+    // ---- launches: molecules in chunks (gridDim.y limit; optionally pre-pass on the side stream, one chunk ahead) ----
+    const int max_mol = 65535 / ncc;
     int nchunk = (r.B + max_mol - 1) / max_mol;
     if (h->pipeline > 1 && r.B >= 4 * h->pipeline) nchunk = std::max(nchunk, h->pipeline);
+    const bool side_stream = (nchunk > 1);
     hipStream_t pre = s;
-    if (nchunk > 1) {
+    if (side_stream) {
         if (!h->side) HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
         if (!h->ev_in) HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
         while ((int)h->ev_pre.size() < nchunk) {
@@ -406,45 +445,34 @@ int run(mvx_handle *h, const RunArgs &r) {
         HIP_TRY(hipEventRecord(h->ev_in, s));
         HIP_TRY(hipStreamWaitEvent(pre, h->ev_in, 0));
     }
-    uint2 *d_xlist = reinterpret_cast<uint2 *>(h->xlist.p);
+    auto chunk_begin = [&](int k) { return (int)((int64_t)r.B * k / nchunk); };
     for (int k = 0; k < nchunk; ++k) {
-        const int b0 = (int)((int64_t)r.B * k / nchunk), b1 = (int)((int64_t)r.B * (k + 1) / nchunk);
+        const int b0 = chunk_begin(k), b1 = chunk_begin(k + 1);
         pa.first = r.offsets[b0];
         pa.total = r.offsets[b1];
         HIP_TRY(launch_prep(pa, pre));
         // (the first launch also zeroes the overflow counter)
-        HIP_TRY(launch_xbin(pa.xp, d_off, b0, b1 - b0, max_atoms, nsx, nsy, nzc, NW, d_xlist, d_slist, d_slist_ext,
-                            k == 0 ? va.overflow : nullptr, pre));
-        if (nchunk > 1) HIP_TRY(hipEventRecord(h->ev_pre[k], pre));
-    }
-    for (int k = 0; k < nchunk && !f64; ++k) {
-        const int b0 = (int)((int64_t)r.B * k / nchunk), b1 = (int)((int64_t)r.B * (k + 1) / nchunk);
-        if (nchunk > 1) HIP_TRY(hipStreamWaitEvent(s, h->ev_pre[k], 0));
-        const bool timed = h->profiling && h->ev_count < MVX_PROFILE_RING;
-        if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count], s));
-        va.p.b0 = b0;
-        HIP_TRY(launch_voxelize(va, b1 - b0, ct, gauss, chanwise, lane_range, s));
-        if (timed) { // the bracket holds voxelize_kernel alone (what rocprofv3 reports under that name)
-            HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count + 1], s));
-            ++h->ev_count;
-        }
-        // (a slab overflows at min(8 NW, 64) candidates: impossible when no molecule has that many atoms)
-        if (k == nchunk - 1 && max_atoms >= std::min(8 * NW, 64)) HIP_TRY(launch_voxelize_dense(va, ct, gauss, chanwise, lane_range, s));
+        HIP_TRY(launch_xbin(pa.xp, in.offsets, b0, b1 - b0, max_atoms, sp.nsx, sp.nsy, sp.nzc, sp.NW, d_xlist, d_slist,
+                            d_slist_ext, k == 0 ? va.overflow : nullptr, pre));
+        if (side_stream) HIP_TRY(hipEventRecord(h->ev_pre[k], pre));
     }
     if (f64) { // float64 grids: one launch of the general slab loop over the whole batch
-        for (int k = 0; k < nchunk && nchunk > 1; ++k) HIP_TRY(hipStreamWaitEvent(s, h->ev_pre[k], 0));
-        const bool timed = h->profiling && h->ev_count < MVX_PROFILE_RING;
-        if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count], s));
-        va.p.b0 = 0;
-        HIP_TRY(launch_voxelize64(va, ct, gauss, chanwise, lane_range, s));
-        if (timed) {
-            HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count + 1], s));
-            ++h->ev_count;
+        for (int k = 0; k < nchunk && side_stream; ++k) HIP_TRY(hipStreamWaitEvent(s, h->ev_pre[k], 0));
+        if ((rc = timed_launch(h, s, [&] { return launch_voxelize64(va, ct, gauss, chanwise, lane_range, s); }))) return rc;
+    } else {
+        for (int k = 0; k < nchunk; ++k) {
+            const int b0 = chunk_begin(k), b1 = chunk_begin(k + 1);
+            if (side_stream) HIP_TRY(hipStreamWaitEvent(s, h->ev_pre[k], 0));
+            va.p.b0 = b0;
+            // the bracket holds voxelize_kernel alone (what rocprofv3 reports under that name)
+            if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, ct, gauss, chanwise, lane_range, s); }))) return rc;
         }
+        // a slab overflows at min(8 NW, 64) candidates: impossible when no molecule has that many atoms
+        if (max_atoms >= std::min(8 * sp.NW, 64)) HIP_TRY(launch_voxelize_dense(va, ct, gauss, chanwise, lane_range, s));
     }
 
-    HIP_TRY(hipEventRecord(slot->done, s));
-    slot->in_flight = true;
+    HIP_TRY(hipEventRecord(in.slot->done, s));
+    in.slot->in_flight = true;
 
     if (r.out_kind == MVX_HOST) {
         HIP_TRY(hipMemcpyAsync(r.out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
