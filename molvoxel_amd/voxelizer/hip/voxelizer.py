@@ -67,6 +67,7 @@ class Voxelizer(BaseVoxelizer):
         self._device_index = self._resolve_device(device)
         self._handle = _lib.Handle()
         self._types_cache = None
+        self._types_i32 = None
         self._has_torch_cuda = torch is not None and torch.cuda.is_available()  # asked on every call otherwise
         cfg = _lib.MvxConfig(
             float(resolution),
@@ -183,7 +184,7 @@ class Voxelizer(BaseVoxelizer):
                     device=self.device, dtype=self._tfp).contiguous()
             elif chan_kind == "types":
                 t = chan if _is_torch(chan) else torch.as_tensor(np.asarray(chan), device=self.device)
-                ch = t.to(device=self.device).to(torch.int16).to(torch.int32).contiguous()  # int16 like numpy/voxelizer.py:269
+                ch = self._types_as_int32(t)
             r = None
             if not _np_isscalar(radii):
                 r = (radii if _is_torch(radii) else torch.as_tensor(np.asarray(radii), device=self.device)).to(
@@ -321,17 +322,27 @@ class Voxelizer(BaseVoxelizer):
             C.cast(C.byref(xf), C.c_void_p), self._ptr(buf), in_kind, out_kind, self._stream()))
         return self._finish_out(buf, ret, how)
 
+    def _types_as_int32(self, t):
+        """Device types in the ABI's int32, through int16 like the reference's cast (numpy/voxelizer.py:269).
+        The converted tensor is remembered while the same unmodified tensor keeps coming (two cast kernels per call
+        otherwise)."""
+        hit = self._types_i32
+        if hit is None or hit[0] is not t or hit[1] != t._version:
+            # (the source tensor is held, not its address: a freed tensor's memory can come back with other content)
+            hit = self._types_i32 = (t, t._version, t.to(device=self.device).to(torch.int16).to(torch.int32).contiguous())
+        return hit[2]
+
     def _types_extent(self, types):
         """(min, max) of the type indices. For a device tensor this costs a kernel and a synchronisation, so the
         answer is remembered for as long as the same tensor is passed unmodified (torch bumps `_version` on every
         in-place write) - the per-molecule loop of test/test_time_numpy.py:11-15 asks thousands of times."""
         if not _is_torch(types):
             return int(types.min()), int(types.max())
-        key = (types.data_ptr(), types.numel(), types._version, str(types.dtype))
-        if self._types_cache is None or self._types_cache[0] != key:
+        hit = self._types_cache
+        if hit is None or hit[0] is not types or hit[1] != types._version:
             lo, hi = torch.aminmax(types)
-            self._types_cache = (key, int(lo), int(hi))
-        return self._types_cache[1], self._types_cache[2]
+            hit = self._types_cache = (types, types._version, int(lo), int(hi))
+        return hit[2], hit[3]
 
     def _check_args_types(self, coords, types, radii, out_grid=None):
         V = coords.shape[0]

@@ -483,3 +483,39 @@ def test_offsets_cache_across_calls_and_streams(mv):
         batch([30, 20, 10])  # same offsets, other stream: uploaded again
         batch([5, 5, 50])
     torch.cuda.synchronize()
+
+
+def test_device_types_caches_follow_in_place_writes_and_new_tensors(mv):
+    """The cached (min, max) / int32 copy of a device `types` tensor must not outlive its content: in-place writes
+    bump torch's version counter; a new tensor is a new object even when the allocator hands back the same address."""
+    import torch
+
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(8)
+    D = 16
+    xyz = rng.uniform(-3, 3, (40, 3))
+    v = mv.create_voxelizer(0.5, D, "scalar", "binary", "hip")
+    coords = v.asarray(xyz, "coords")
+    t_np = rng.integers(0, 3, 40)
+    types = v.asarray(t_np, "types")
+
+    def check(t_dev, t_host):
+        out = v.forward_types(coords, None, t_dev, 1.0).cpu().numpy()
+        assert np.array_equal(out, c_oracle.voxelize(xyz, t_host, 1.0, dimension=D, density="binary"))
+
+    check(types, t_np)
+    check(types, t_np)  # served from the caches
+    types[5] = 6  # in place: more channels now
+    t_np = t_np.copy()
+    t_np[5] = 6
+    check(types, t_np)
+    addr = types.data_ptr()
+    del types
+    for _ in range(4):  # fresh tensors, very likely at the address just freed
+        t_np = rng.integers(0, 5, 40)
+        fresh = v.asarray(t_np, "types")
+        check(fresh, t_np)
+        same_addr = fresh.data_ptr() == addr
+        del fresh
+    assert isinstance(same_addr, bool)

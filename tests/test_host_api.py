@@ -163,3 +163,41 @@ def test_shard_bounds_partition():
     off = np.cumsum(np.concatenate([[0], wts]))
     lo = local_offsets(off, 10, 20)
     assert lo[0] == 0 and lo[-1] == wts[10:20].sum() and len(lo) == 11
+
+
+def test_contract_module_geometry_and_switches():
+    """molvoxel_amd/voxelizer/contract.py against the reference's documented behaviour (base/voxelizer.py:15-97)."""
+    from molvoxel_amd.voxelizer.contract import GridGeometry, VoxelizerContract
+
+    geo = GridGeometry(0.5, 64)
+    assert geo.width == 31.5 and geo.upper_bound == 15.75 and geo.lower_bound == -15.75  # SURVEY.md a2
+    assert geo.spatial_dimension == (64, 64, 64) and geo.grid_dimension(5) == (5, 64, 64, 64)
+
+    class Dummy(VoxelizerContract):
+        changed = 0
+
+        def _density_changed(self):
+            self.changed += 1
+
+    v = Dummy(0.4, 24, "atom-wise", "gaussian", sigma=0.8)
+    assert (v.resolution, v.dimension, v.width) == (0.4, 24, 0.4 * 23) and v._sigma == 0.8
+    assert v.is_radii_type_atom_wise and not v.is_radii_type_scalar and not v.is_radii_type_channel_wise
+    v.radii_type = "channel-wise"
+    assert v.is_radii_type_channel_wise and v.radii_type == "channel-wise"
+    with pytest.raises(AssertionError):
+        v.radii_type = "per-atom"
+    v.density_type = "binary"
+    assert v.is_density_type_binary and v.changed == 1
+    v.density_type = "gaussian"  # the setter cannot carry a sigma: back to the default (base/voxelizer.py:65-70)
+    assert v.is_density_type_gaussian and v._sigma == 0.5 and v.changed == 2
+    with pytest.raises(AssertionError):
+        Dummy(0.5, 8, "scalar", "box")
+    # forward dispatches on the channel argument
+    calls = []
+    v.forward_single = lambda *a: calls.append(("single", len(a)))
+    v.forward_types = lambda *a: calls.append(("types", len(a)))
+    v.forward_features = lambda *a: calls.append(("features", len(a)))
+    v.forward(np.zeros((2, 3)), None, None, 1.0)
+    v(np.zeros((2, 3)), None, np.zeros(2, int), 1.0)
+    v.forward(np.zeros((2, 3)), None, np.zeros((2, 4)), 1.0, 0.5, True, None)
+    assert calls == [("single", 6), ("types", 7), ("features", 7)]

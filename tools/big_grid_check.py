@@ -1,4 +1,4 @@
-"""One-off parity check on a large grid (python3 scratch/big_grid_check.py [D] [N])."""
+"""One-off parity check on a large grid (python3 tools/big_grid_check.py [D] [N])."""
 import sys
 import time
 

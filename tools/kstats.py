@@ -1,4 +1,4 @@
-"""Print per-kernel average durations from a rocprofv3 --stats output directory (python3 scratch/kstats.py DIR)."""
+"""Print per-kernel average durations from a rocprofv3 --stats output directory (python3 tools/kstats.py DIR)."""
 import csv
 import glob
 import sys

@@ -1,4 +1,4 @@
-"""Where a single forward() call spends its host time (python3 scratch/latency.py)."""
+"""Where a single forward() call spends its host time (python3 tools/latency.py)."""
 import cProfile
 import pstats
 import sys

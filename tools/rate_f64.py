@@ -1,4 +1,4 @@
-"""float64 grids on cfg-2 geometry (python3 scratch/rate_f64.py)."""
+"""float64 grids on cfg-2 geometry (python3 tools/rate_f64.py)."""
 import sys
 
 import numpy as np

@@ -1,4 +1,4 @@
-"""Voxelize-kernel rate on cfg-2 geometry for several channel counts (python3 scratch/rate_vs_channels.py)."""
+"""Voxelize-kernel rate on cfg-2 geometry for several channel counts (python3 tools/rate_vs_channels.py)."""
 import sys
 
 import numpy as np

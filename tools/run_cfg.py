@@ -1,4 +1,4 @@
-"""rocprofv3 helper: run one bench_configs row in a loop (python3 scratch/run_cfg.py cfg4 128 50)."""
+"""rocprofv3 helper: run one bench_configs row in a loop (python3 tools/run_cfg.py cfg4 128 50)."""
 import sys
 
 import numpy as np
