@@ -201,3 +201,27 @@ def test_contract_module_geometry_and_switches():
     v(np.zeros((2, 3)), None, np.zeros(2, int), 1.0)
     v.forward(np.zeros((2, 3)), None, np.zeros((2, 4)), 1.0, 0.5, True, None)
     assert calls == [("single", 6), ("types", 7), ("features", 7)]
+
+
+def test_header_is_valid_c_and_matches_the_python_structs(tmp_path):
+    """include/mvx.h must compile as plain C (the boundary is a C ABI) and agree with the ctypes layouts."""
+    import shutil
+    import subprocess
+
+    from molvoxel_amd.voxelizer.hip import _lib
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "mvx.h"\n'
+        "int main(void) {\n"
+        '  printf("%zu %zu %zu %zu %zu %d\\n", sizeof(mvx_config), sizeof(mvx_xform), offsetof(mvx_config, precision),\n'
+        "         offsetof(mvx_xform, trans), offsetof(mvx_xform, flags), MVX_VERSION);\n"
+        "  return 0;\n}\n")
+    exe = tmp_path / "abi"
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert [int(v) for v in out] == [C.sizeof(_lib.MvxConfig), C.sizeof(_lib.MvxXform), _lib.MvxConfig.precision.offset,
+                                     _lib.MvxXform.trans.offset, _lib.MvxXform.flags.offset, 110]
