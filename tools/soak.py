@@ -1,4 +1,8 @@
-"""Long randomised parity run beyond the committed fuzz seeds (python3 tools/soak.py FIRST COUNT)."""
+"""Long randomised parity run beyond the committed fuzz seeds.
+
+    python3 tools/soak.py FIRST COUNT            single-molecule configurations (tests/test_hip_fuzz._draw)
+    python3 tools/soak.py batches FIRST COUNT    ragged batches (tests/test_hip_fuzz.test_random_batches with other seeds)
+"""
 import importlib.util
 import sys
 import time
@@ -10,6 +14,21 @@ spec = importlib.util.spec_from_file_location("fz", "tests/test_hip_fuzz.py")
 fz = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(fz)
 import molvoxel_amd as mv
+
+if sys.argv[1] == "batches":
+    first, count = int(sys.argv[2]), int(sys.argv[3])
+    bad, t0 = [], time.time()
+    body = fz.test_random_batches.__wrapped__ if hasattr(fz.test_random_batches, "__wrapped__") else fz.test_random_batches
+    for seed in range(first, first + count):
+        try:
+            body(seed)
+        except Exception as e:  # noqa: BLE001
+            bad.append(seed)
+            print("MISMATCH batch seed", seed, repr(e)[:300], flush=True)
+        if (seed - first) % 50 == 49:
+            print(f"{seed - first + 1} batches, {len(bad)} bad, {time.time() - t0:.0f}s", flush=True)
+    print("done", count, "batches; bad seeds:", bad)
+    sys.exit(0)
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
 bad, t0 = [], time.time()
