@@ -225,3 +225,40 @@ def test_header_is_valid_c_and_matches_the_python_structs(tmp_path):
     out = subprocess.check_output([str(exe)]).decode().split()
     assert [int(v) for v in out] == [C.sizeof(_lib.MvxConfig), C.sizeof(_lib.MvxXform), _lib.MvxConfig.precision.offset,
                                      _lib.MvxXform.trans.offset, _lib.MvxXform.flags.offset, 110]
+
+
+def _build_c_demo(tmp_path):
+    import shutil
+    import subprocess
+
+    from molvoxel_amd.voxelizer.hip import _lib
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    exe = tmp_path / "c_abi_demo"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call([gcc, "-std=c99", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L", libdir, "-lmvx_hip",
+                           f"-Wl,-rpath,{libdir}", "-lm", "-o", str(exe)])
+    return str(exe)
+
+
+def test_c_program_links_against_the_abi_and_fails_loudly_without_a_gpu(tmp_path):
+    import subprocess
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([_build_c_demo(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_program_runs_through_the_abi(tmp_path):
+    """examples/c_abi_demo.c: plain C caller, device buffers from mvx_alloc, result against a brute-force host loop."""
+    import subprocess
+
+    r = subprocess.run([_build_c_demo(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
