@@ -519,3 +519,35 @@ def test_device_types_caches_follow_in_place_writes_and_new_tensors(mv):
         same_addr = fresh.data_ptr() == addr
         del fresh
     assert isinstance(same_addr, bool)
+
+
+def test_argument_dtypes_and_layouts_are_normalised(mv):
+    """What the reference's asarray/_dtypechange would accept (numpy/voxelizer.py:562-583): float32 coords, float64
+    features, int64 types, Fortran-ordered arrays, a non-contiguous or wrongly typed out_grid (still the object
+    returned, filled through a temporary)."""
+    import torch
+
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(17)
+    D = 20
+    xyz32 = rng.uniform(-4, 4, (60, 3)).astype(np.float32)
+    feats64 = np.asfortranarray(rng.random((60, 6)))
+    types64 = rng.integers(0, 4, 60).astype(np.int64)
+    v = mv.create_voxelizer(0.5, D, "scalar", "gaussian", "hip", output="numpy")
+    ref_f = c_oracle.voxelize(xyz32.astype(np.float64), feats64.astype(np.float32), 1.0, dimension=D)
+    ref_t = c_oracle.voxelize(xyz32.astype(np.float64), types64, 1.0, dimension=D)
+    _compare(v.forward_features(xyz32, None, feats64, 1.0), ref_f, exact=False)
+    _compare(v.forward_types(xyz32, None, types64, 1.0), ref_t, exact=False)
+    big = np.zeros((6, D, D, 2 * D), np.float32)
+    view = big[..., ::2]  # non-contiguous
+    assert v.forward_features(xyz32, None, feats64, 1.0, out_grid=view) is view
+    _compare(np.ascontiguousarray(view), ref_f, exact=False)
+    out64 = np.empty((6, D, D, D), np.float64)  # wrong dtype: converted on the way back
+    assert v.forward_features(xyz32, None, feats64, 1.0, out_grid=out64) is out64
+    assert np.abs(out64 - ref_f).max() <= GAUSS_TOL
+    vt = mv.create_voxelizer(0.5, D, "scalar", "gaussian", "hip")  # torch in / out
+    tview = torch.zeros((6, D, D, 2 * D), device=vt.device)[..., ::2]
+    got = vt.forward_features(torch.as_tensor(xyz32), None, torch.as_tensor(feats64), 1.0, out_grid=tview)
+    assert got is tview
+    _compare(tview.contiguous().cpu().numpy(), ref_f, exact=False)
