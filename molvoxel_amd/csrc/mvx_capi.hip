@@ -421,6 +421,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.dcap = f64 ? 64 : voxelize_dcap(ct, sp.NW);
     va.p.vec_store = (D % 4 == 0) ? 1 : 0;
     va.p.store_kind = h->store_kind;
+    va.p.pace = (nslabs * (size_t)ncc > 4096) ? 1 : 0;
     va.p.sigma = h->cfg.sigma;
     // a sub-tile lies inside one reference block when its edges divide blockdim (or there is a single block):
     // the block cull is then wave-uniform and already folded into the candidate ranges.

@@ -78,6 +78,7 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
     int32_t dcap;          // candidate rows staged per round
     int32_t vec_store;     // D % 4 == 0 and out 16-B aligned
     int32_t store_kind;    // 0 plain, 1 nt, 2 sc1 (MVX_STORE)
+    int32_t pace;          // 1: empty slabs hold their stores back ~1.7 us (launches of more than 4096 workgroups)
     double sigma;          // float64 grids: the Gaussian sigma as the reference holds it (python float)
 };
 
