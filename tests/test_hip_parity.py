@@ -551,3 +551,51 @@ def test_argument_dtypes_and_layouts_are_normalised(mv):
     got = vt.forward_features(torch.as_tensor(xyz32), None, torch.as_tensor(feats64), 1.0, out_grid=tview)
     assert got is tview
     _compare(tview.contiguous().cpu().numpy(), ref_f, exact=False)
+
+
+def test_reference_readme_quick_start(mv):
+    """README.md:48-98 of the reference with `library='hip'`: the 10gs ligand through forward_single / forward_types /
+    forward_features, once with numpy arrays (boolean feature matrix included) and once with float32 / int64 CUDA
+    tensors."""
+    import os
+
+    import torch
+
+    from molvoxel_amd.etc import mol as M
+    from oracle import c_oracle
+
+    lig = M.read_sdf(os.path.join(goldens.GOLD, "10gs", "10gs_ligand.sdf"))[0]
+    channels = {"C": 0, "N": 1, "O": 2, "S": 3}
+    coords = lig.coords
+    center = coords.mean(axis=0)
+    atom_types = np.array([channels[a.GetSymbol()] for a in lig.atoms()])
+    atom_features = np.array([[a.GetSymbol() == "C", a.GetSymbol() == "N", a.GetSymbol() == "O", a.GetSymbol() == "S",
+                               a.GetIsAromatic()] for a in lig.atoms()])  # bool (V, 5)
+    assert atom_features.dtype == bool
+    voxelizer = mv.create_voxelizer(library="hip", output="numpy")  # defaults: 0.5, 64, scalar, gaussian sigma 0.5
+    moved = coords - center
+    ref = {
+        "single": c_oracle.voxelize(moved, None, 1.0, dimension=64),
+        "types": c_oracle.voxelize(moved, atom_types, 1.0, dimension=64),
+        "features": c_oracle.voxelize(moved, atom_features.astype(np.float32), 1.0, dimension=64),
+    }
+    img = {
+        "single": voxelizer.forward_single(coords, center, 1.0),
+        "types": voxelizer.forward_types(coords, center, atom_types, 1.0),
+        "features": voxelizer.forward_features(coords, center, atom_features, 1.0),
+    }
+    assert img["single"].shape == (1, 64, 64, 64) and img["types"].shape == (4, 64, 64, 64) and img["features"].shape == (5, 64, 64, 64)
+    for k in ref:
+        _compare(img[k], ref[k], exact=False)
+    # "PyTorch - Cuda Available" (README.md:84-98)
+    vt = mv.create_voxelizer(library="hip", device="cuda")
+    tc = torch.FloatTensor(coords).to("cuda")
+    tcen = torch.FloatTensor(center).to("cuda")
+    ttypes = torch.LongTensor(atom_types).to("cuda")
+    tfeat = torch.FloatTensor(atom_features.astype(np.float32)).to("cuda")
+    moved32 = tc.double().cpu().numpy() - tcen.double().cpu().numpy()  # what float32 inputs mean in float64
+    out = vt.forward_features(tc, tcen, tfeat, 1.0)
+    assert out.is_cuda and tuple(out.shape) == (5, 64, 64, 64)
+    _compare(out.cpu().numpy(), c_oracle.voxelize(moved32, atom_features.astype(np.float32), 1.0, dimension=64), exact=False)
+    _compare(vt.forward_types(tc, tcen, ttypes, 1.0).cpu().numpy(), c_oracle.voxelize(moved32, atom_types, 1.0, dimension=64), exact=False)
+    _compare(vt.forward_single(tc, tcen, 1.0).cpu().numpy(), c_oracle.voxelize(moved32, None, 1.0, dimension=64), exact=False)
