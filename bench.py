@@ -84,6 +84,24 @@ def cpu_baseline(budget_s: float):
     return port
 
 
+def parity_spot(out, coords, feats, picks, radius=1.0, dimension=64, sigma=0.5):
+    """Post-timing spot check (outside the timed region): the grids of the molecules `picks` of the batch that was
+    just timed against the CPU oracle: membership identical, |d| <= 5e-6 * max(1, |ref|) per voxel
+    (tests/tolerance.py). Returns "ok" or "FAIL: ..."."""
+    from oracle import c_oracle
+
+    for b in picks:
+        ref = c_oracle.voxelize(coords[b], feats[b], radius, dimension=dimension, sigma=sigma)
+        got = out[b].cpu().numpy()
+        bad = int(np.not_equal(got != 0, ref != 0).sum())
+        if bad:
+            return f"FAIL: molecule {b}: membership differs in {bad} voxels"
+        ex = float((np.abs(got - ref) / (5e-6 * np.maximum(1.0, np.abs(ref)))).max())
+        if ex > 1.0:
+            return f"FAIL: molecule {b}: error {ex:.3g} x the tolerance"
+    return "ok"
+
+
 def load_pmc_traffic(molecules_per_launch: int):
     """HBM bytes per voxelize launch from the committed rocprofv3 --pmc summary, if it matches this config."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -97,12 +115,27 @@ def load_pmc_traffic(molecules_per_launch: int):
     return None
 
 
+def make_cfg4_shard(total: int, rank: int, world: int):
+    """cfg-4 (BASELINE.json configs[3]): `total` ligands (40-60 atoms, C = 16) cut into contiguous shards balanced by
+    atom count (molvoxel_amd/sharding.py); returns this rank's molecules."""
+    from molvoxel_amd import sharding
+    from molvoxel_amd import workloads as W
+
+    wl = W.cfg4(batch=total)
+    bounds = sharding.balanced_shard_bounds([c.shape[0] for c in wl.coords], world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    return wl, lo, hi
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=("cfg2", "cfg4"), default="cfg2",
+                    help="cfg2 = the headline metric (default); cfg4 = 1024 ligands x world size, sharded by atom count")
     ap.add_argument("--batch", type=int, default=256, help="cfg-2 molecules per GPU per step (8.6 GB of grids at 256)")
+    ap.add_argument("--ligands-per-gpu", type=int, default=128, help="cfg-4: the job holds this many ligands per rank")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables)")
     args = ap.parse_args()
 
@@ -129,13 +162,26 @@ def main():
 
     import molvoxel_amd
 
-    B = args.batch
-    wl, coords, feats = make_batch(B, rank)
     vox = molvoxel_amd.create_voxelizer(0.5, 64, "scalar", "gaussian", library="hip", device=dev_index)
-    offsets = np.arange(B + 1, dtype=np.int64) * 4000
+    if args.workload == "cfg2":
+        B = args.batch
+        wl, coords, feats = make_batch(B, rank)
+        C_ = 32
+        kernel_name = "voxelize_kernel<32,gauss>"
+        workload = "cfg2: forward_features, gaussian sigma=0.5, scalar radius 1.0, C=32, 64^3, N=4000 atoms/molecule"
+        job_molecules = args.gpus * B
+    else:
+        wl4, lo, hi = make_cfg4_shard(args.ligands_per_gpu * world, rank, world)
+        coords, feats = wl4.coords[lo:hi], wl4.channels[lo:hi]
+        wl, B, C_ = wl4, hi - lo, 16
+        kernel_name = "voxelize_kernel<16,gauss>"
+        workload = (f"cfg4: {args.ligands_per_gpu * world} ligands (40-60 atoms), forward_features, gaussian sigma=0.5, "
+                    "scalar radius 1.0, C=16, 64^3, sharded by atom count")
+        job_molecules = args.ligands_per_gpu * world
+    offsets = np.cumsum([0] + [c.shape[0] for c in coords]).astype(np.int64)
     d_coords = vox.asarray(np.concatenate(coords), "coords")
     d_feats = vox.asarray(np.concatenate(feats), "features")
-    out = vox.get_empty_grid(32, batch_size=B)
+    out = vox.get_empty_grid(C_, batch_size=B)
 
     def step():
         vox.forward_batch(d_coords, offsets, None, d_feats, 1.0, out_grid=out)
@@ -157,34 +203,51 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = vox.read_kernel_times_ms()
     vox.set_profiling(False)
+    my_elapsed = elapsed
 
+    rank_ms = [1e3 * my_elapsed / args.steps]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        on = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=on)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        allms = [torch.zeros(1, dtype=torch.float64, device=on) for _ in range(world)]
+        dist.all_gather(allms, torch.tensor([1e3 * my_elapsed / args.steps], dtype=torch.float64, device=on))
+        rank_ms = [float(x.item()) for x in allms]
+
+    # post-timing spot check of the grids the timed steps left behind (rank 0, outside the timed region)
+    spot = None
+    if rank == 0:
+        picks = sorted({0, B // 2, B - 1})
+        spot = parity_spot(out, coords, feats, picks)
 
     if rank == 0:
-        # the library cuts a step's batch into equal chunks of molecules (pre-pass of chunk k+1 overlaps the
-        # voxelize launch of chunk k): per launch = B / launches_per_step molecules x (4*C*D^3 + N*(24 + 4*C + 4))
+        # the library cuts a step's batch into equal chunks of molecules only beyond 65535 (molecule, channel chunk)
+        # pairs; per launch = B / launches_per_step molecules x (4*C*D^3 + N*(24 + 4*C + 4))
         lps = max(1, len(kernel_ms) // args.steps)
-        alg_bytes = (B // lps) * wl.algorithmic_bytes(0)
-        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        step_bytes = sum(4 * C_ * 64**3 + c.shape[0] * (24 + 4 * C_ + 4) for c in coords)
+        alg_bytes = step_bytes // lps
+        k = np.sort(np.asarray(kernel_ms, dtype=np.float64)) if kernel_ms else np.array([float("nan")])
+        k_ms = float(np.mean(k))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        ms_per_step = 1e3 * elapsed / args.steps
+        traffic = load_pmc_traffic(B // lps) if args.workload == "cfg2" else None
         res = {
-            "metric": "molecules/sec + achieved HBM GB/s, forward_features C=32 64^3 N=4000",
-            "value": args.gpus * B * args.steps / elapsed,
+            "metric": "molecules/sec + achieved HBM GB/s, forward_features C=32 64^3 N=4000" if args.workload == "cfg2"
+                      else "molecules/sec, batch of ligands (cfg-4), forward_features C=16 64^3 N~50",
+            "value": job_molecules * args.steps / elapsed,
             "unit": "molecules/s",
             "n_gpus": args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "cfg2: forward_features, gaussian sigma=0.5, scalar radius 1.0, C=32, 64^3, N=4000 atoms/molecule",
+                "workload": workload,
                 "molecules_per_gpu_per_step": B,
                 "inputs": "HBM-resident (torch CUDA tensors), outputs left in HBM",
                 "geometry_dtype": "f64",
@@ -192,20 +255,29 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "voxelize_kernel<32,gauss>",
+                "kernel": kernel_name,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
+                "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "kernel_ms_avg": k_ms,
+                "kernel_ms_min": float(k[0]),
+                "kernel_ms_p50": float(k[len(k) // 2]),
+                "kernel_ms_max": float(k[-1]),
                 "kernel_launches_timed": len(kernel_ms),
                 "launches_per_step": lps,
                 "molecules_per_launch": B // lps,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "traffic": load_pmc_traffic(B // lps),
+                "traffic": traffic,
+                "traffic_source": None if traffic is None else
+                                  "profiles/pmc_latest.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this command "
+                                  "on the builder's box; replayed here, not measured in this run)",
             },
+            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+            "parity_spot": spot,
         }
-        if args.gpus == 1 and args.cpu_seconds > 0:
+        if args.gpus == 1 and args.cpu_seconds > 0 and args.workload == "cfg2":
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(res), flush=True)
     if dist is not None:

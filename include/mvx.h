@@ -13,11 +13,15 @@
  *     thread-local message for the last failure on the calling thread.
  *   - no ownership transfer: every buffer is caller-owned. Pointers are tagged host/device by
  *     the *_kind arguments (MVX_HOST / MVX_DEVICE). Device pointers must belong to the handle's
- *     device; `out` must be 16-byte aligned.
+ *     device. A 16-byte aligned `out` with dimension % 4 == 0 gets 16-B stores; any other
+ *     float-aligned `out` (e.g. slice i of a batch grid of odd dimension) is written with scalar stores.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). With MVX_DEVICE
  *     outputs the call is asynchronous on that stream; with MVX_HOST outputs it returns after
  *     the copy back has completed.
- *   - a handle is not re-entrant: use one handle per host thread / per stream.
+ *   - a handle is not re-entrant: one host thread at a time. Calls may arrive on different streams:
+ *     the handle's workspace is shared, so a call on another stream than the previous call's first
+ *     makes its stream wait for the previous stream (hipStreamWaitEvent; no host synchronisation).
+ *     A stream must stay alive until the next call on the handle (or mvx_destroy) has returned.
  *   - argument-shape errors are the Python layer's AssertionErrors (same messages as the
  *     reference, molvoxel/voxelizer/numpy/voxelizer.py:181-192, 327-342, 443-455) and are
  *     raised before the call; this library only validates what it needs to stay memory-safe.
@@ -185,6 +189,12 @@ int mvx_stream_sync(mvx_handle *h, void *stream);
  * k float; type int32; x/y/z admitted voxel ranges as lo | hi << 16; 12 B pad) to host memory.
  * Synchronises the stream. Lets the tests check the prep stage (transform, culls, thresholds) alone. */
 int mvx_debug_read_records(mvx_handle *h, void *host_dst, int64_t n, void *stream);
+/* Testing aid: explicit per-handle switches for code paths production sizes rarely reach. The library itself reads
+ * no environment variable.
+ *   "chunks" = k (1..16): cut batches of >= 4k molecules into k molecule chunks whose pre-pass runs on a side stream
+ *              one chunk ahead (the loop that otherwise only runs beyond 65535 (molecule, channel chunk) pairs);
+ *   "max_ct" = 1..32: upper bound on the channels one workgroup accumulates (more channel chunks). */
+int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value);
 #ifdef __cplusplus
 }
 #endif

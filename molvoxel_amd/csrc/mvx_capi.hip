@@ -72,7 +72,12 @@ struct mvx_handle {
     int pipeline = 1;
     std::vector<char> meta_last; // host copy of the offsets the device meta buffer holds
     bool meta_valid = false;
-    hipStream_t meta_stream = nullptr;
+    // Stream hand-over: every call reuses the handle's workspace, ordered by the caller's stream. When a call arrives
+    // on another stream than the previous one, the new stream first waits for everything the old stream holds
+    // (event recorded on the old stream at that moment), so back-to-back calls on different streams never race.
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+    hipEvent_t ev_switch = nullptr;
     hipStream_t side = nullptr;
     hipEvent_t ev_in = nullptr;
     std::vector<hipEvent_t> ev_pre;
@@ -170,6 +175,23 @@ struct RunArgs {
     hipStream_t stream;
 };
 
+// Orders this call after the previous call's work when the caller switched streams (see mvx_handle::last_stream).
+int adopt_stream(mvx_handle *h, hipStream_t s) {
+    if (h->used && h->last_stream != s) {
+        if (!h->ev_switch) HIP_TRY(hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming));
+        // a stream the caller has destroyed meanwhile cannot be recorded on: fall back to a device-wide wait
+        if (hipEventRecord(h->ev_switch, h->last_stream) == hipSuccess) {
+            HIP_TRY(hipStreamWaitEvent(s, h->ev_switch, 0));
+        } else {
+            (void)hipGetLastError();
+            HIP_TRY(hipDeviceSynchronize());
+        }
+    }
+    h->last_stream = s;
+    h->used = true;
+    return MVX_OK;
+}
+
 // ---- 1. what the library checks itself (shapes are the Python layer's job) -----------------------------------------
 int validate(const mvx_handle *h, const RunArgs &r, int64_t &total, int64_t &max_atoms) {
     if (!h) return fail(MVX_ERR_INVALID, "null handle");
@@ -195,8 +217,6 @@ int validate(const mvx_handle *h, const RunArgs &r, int64_t &total, int64_t &max
         return fail(MVX_ERR_INVALID, "radii array required");
     if (total > 0 && r.mode != MODE_SINGLE && !r.channels) return fail(MVX_ERR_INVALID, "channels must not be null");
     if (total >= (int64_t)1 << 31) return fail(MVX_ERR_INVALID, "too many atoms");
-    if (r.out_kind == MVX_DEVICE && (reinterpret_cast<uintptr_t>(r.out) & 15u) != 0)
-        return fail(MVX_ERR_INVALID, "device out pointer must be 16-byte aligned");
     return MVX_OK;
 }
 
@@ -233,15 +253,14 @@ int stage_inputs(mvx_handle *h, const RunArgs &r, int64_t total, size_t esz, hip
     // offsets (+ transforms) go to the device only when they differ from what the last call left there
     // (same-shaped batches, the common case in a training loop, skip a 5 us copy kernel)
     const size_t meta_used = (size_t)(r.B + 1) * sizeof(int64_t);
-    const bool meta_same = !r.xforms && h->meta_valid && h->meta_stream == s && h->meta_last.size() == meta_used &&
+    const bool meta_same = !r.xforms && h->meta_valid && h->meta_last.size() == meta_used &&
                            std::memcmp(h->meta_last.data(), r.offsets, meta_used) == 0;
     if (!meta_same) {
         std::memcpy(pin, r.offsets, meta_used);
         if (r.xforms) std::memcpy(pin + off_bytes, r.xforms, (size_t)r.B * sizeof(mvx_xform));
         HIP_TRY(hipMemcpyAsync(h->meta.p, pin, off_bytes + xf_bytes, hipMemcpyHostToDevice, s));
         h->meta_last.assign(reinterpret_cast<const char *>(r.offsets), reinterpret_cast<const char *>(r.offsets) + meta_used);
-        h->meta_valid = !r.xforms;
-        h->meta_stream = s; // the copy is ordered on this stream only
+        h->meta_valid = !r.xforms; // (a later call on another stream waits for this stream first: adopt_stream)
     }
     in.offsets = reinterpret_cast<const int64_t *>(h->meta.p);
     in.xforms = r.xforms ? reinterpret_cast<const mvx_xform *>((char *)h->meta.p + off_bytes) : nullptr;
@@ -312,6 +331,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
     hipStream_t s = r.stream;
+    if ((rc = adopt_stream(h, s))) return rc;
     const Geom &g = h->g;
     const int D = g.D;
     const bool f64 = (h->cfg.precision == 64);
@@ -419,7 +439,9 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.NW = sp.NW;
     va.p.w_stride = Cpad;
     va.p.dcap = f64 ? 64 : voxelize_dcap(ct, sp.NW);
-    va.p.vec_store = (D % 4 == 0) ? 1 : 0;
+    // 16-B stores need whole float4 groups per row (D % 4 == 0) and a 16-B aligned grid; anything else (odd
+    // dimensions, a slice `grid[i]` of a batch grid whose slices are not 16-B multiples) takes the scalar-store path
+    va.p.vec_store = (D % 4 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) ? 1 : 0;
     va.p.store_kind = h->store_kind;
     va.p.pace = (nslabs * (size_t)ncc > 4096) ? 1 : 0;
     va.p.sigma = h->cfg.sigma;
@@ -527,10 +549,12 @@ int mvx_create(const mvx_config *cfg, mvx_handle **out) {
     h->cfg = *cfg;
     h->device = cfg->device;
     make_geom(h);
+#ifdef MVX_EXPERIMENT // A/B builds only (make EXPERIMENT=1): the shipped library reads no environment variable
     if (const char *env = std::getenv("MVX_NW")) h->force_nw = std::atoi(env);
     if (const char *env = std::getenv("MVX_STORE")) h->store_kind = std::atoi(env);
     if (const char *env = std::getenv("MVX_CT")) h->max_ct = std::max(1, std::min(32, std::atoi(env)));
     if (const char *env = std::getenv("MVX_PIPELINE")) h->pipeline = std::max(1, std::min(16, std::atoi(env)));
+#endif
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) {
         delete h;
@@ -554,6 +578,7 @@ int mvx_destroy(mvx_handle *h) {
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_pre) (void)hipEventDestroy(e);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+    if (h->ev_switch) (void)hipEventDestroy(h->ev_switch);
     if (h->side) (void)hipStreamDestroy(h->side);
     delete h;
     return MVX_OK;
@@ -628,6 +653,7 @@ int mvx_transform_coords(mvx_handle *h, const double *coords, int64_t N, const m
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (int rc0 = adopt_stream(h, s)) return rc0;
     const size_t xf_bytes = align_up(sizeof(mvx_xform), 16);
     const size_t co_bytes = (size_t)N * 3 * sizeof(double);
     const bool host_in = in_kind == MVX_HOST, host_out = out_kind == MVX_HOST;
@@ -705,6 +731,15 @@ int mvx_debug_read_records(mvx_handle *h, void *host_dst, int64_t n, void *strea
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(hipMemcpyAsync(host_dst, h->rec.p, (size_t)n * sizeof(AtomRec), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return MVX_OK;
+}
+
+int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
+    if (!h || !name) return fail(MVX_ERR_INVALID, "null argument");
+    const std::string n(name);
+    if (n == "chunks") h->pipeline = std::max(1, std::min(16, (int)value));
+    else if (n == "max_ct") h->max_ct = std::max(1, std::min(32, (int)value));
+    else return fail(MVX_ERR_INVALID, "unknown option: " + n);
     return MVX_OK;
 }
 

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "csrc")
-LIB_PATH = os.environ.get("MVX_LIB", os.path.join(CSRC, "libmvx_hip.so"))  # MVX_LIB: A/B experiments only
+LIB_PATH = os.path.join(CSRC, "libmvx_hip.so")
 
 MVX_HOST, MVX_DEVICE = 0, 1
 MVX_GAUSSIAN, MVX_BINARY = 0, 1
@@ -62,6 +62,7 @@ SIGNATURES = {
     "mvx_profile_read": (C.c_int, [Handle, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]),
     "mvx_last_kernel_ms": (C.c_int, [Handle, C.POINTER(C.c_float)]),
     "mvx_debug_read_records": (C.c_int, [Handle, _vp, _i64, _vp]),
+    "mvx_debug_set_option": (C.c_int, [Handle, C.c_char_p, _i32]),
     "mvx_alloc": (C.c_int, [Handle, _i64, C.POINTER(C.c_void_p)]),
     "mvx_free": (C.c_int, [Handle, _vp]),
     "mvx_memcpy": (C.c_int, [Handle, _vp, _vp, _i64, _i32, _i32, _vp]),

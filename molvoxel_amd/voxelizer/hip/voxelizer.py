@@ -414,7 +414,12 @@ class Voxelizer(BaseVoxelizer):
                 radii.shape[0] if self.is_radii_type_channel_wise else int(channels.max()) + 1)
         else:
             kind, C_ = "features", channels.shape[1]
+        self._check_args_batch(coords, channels, kind, radii, int(C_))
         c, ch, r, in_kind, keep = self._prepare_inputs(coords, channels, kind, radii)
+        if kind == "types" and self.is_radii_type_channel_wise and r.shape[0] < C_:
+            # channel-wise radii are indexed by type only; pad so the (C,) contract of the ABI holds (as forward_types)
+            pad = int(C_) - r.shape[0]
+            r = torch.cat([r, r.new_ones(pad)]) if _is_torch(r) else np.concatenate([r, np.ones(pad, self.fp)])
         need_xf = centers is not None or random_rotation or (random_translation and random_translation > 0.0)
         xf_ptr = C.c_void_p(0)
         if need_xf:
@@ -449,8 +454,38 @@ class Voxelizer(BaseVoxelizer):
         _lib.check(rc)
         return self._finish_out(buf, ret, how)
 
+    def _check_args_batch(self, coords, channels, kind, radii, C_):
+        """The per-molecule checks (_check_args_features / _types / _single) for atoms stored back to back: the
+        library reads sumN rows of channels and sumN | C radii, so every array must really have them."""
+        V = coords.shape[0]
+        assert coords.ndim == 2 and coords.shape[1] == 3, f"coords does not match dimension: {tuple(coords.shape)} vs {(V, 3)}"
+        if kind == "features":
+            assert channels.shape[0] == V, f"atom features does not match number of atoms: {channels.shape[0]} vs {V}"
+        elif kind == "types":
+            assert tuple(channels.shape) == (V,), f"types does not match dimension: {tuple(channels.shape)} vs {(V,)}"
+        else:
+            assert not self.is_radii_type_channel_wise, "Channel-Wise Radii Type is not supported"
+        if self.is_radii_type_scalar:
+            assert _np_isscalar(radii), "the radii type of voxelizer is `scalar`, radii should be scalar"
+        elif self.is_radii_type_channel_wise:
+            assert not _np_isscalar(radii), f"the radii type of voxelizer is `channel-wise`, radii should be Array[{C_},]"
+            if kind == "features":
+                assert tuple(radii.shape) == (C_,), f"radii does not match dimension (number of channels,): {tuple(radii.shape)} vs {(C_,)}"
+            else:  # types: radii are gathered by type; every type below num_channels needs one
+                assert radii.ndim == 1 and 0 < radii.shape[0] <= C_, f"radii does not match dimension (number of channels,): {tuple(radii.shape)} vs {(C_,)}"
+                if V > 0:
+                    tmax = int(channels.max())
+                    assert tmax < radii.shape[0], f"radii does not match dimension (number of channels,): {tuple(radii.shape)} vs {(tmax + 1,)}"
+        else:
+            assert not _np_isscalar(radii), f"the radii type of voxelizer is `atom-wise`, radii should be Array[{V},]"
+            assert tuple(radii.shape) == (V,), f"radii does not match dimension (number of atoms,): {tuple(radii.shape)} vs {(V,)}"
+
     # ------------------------------------------------------------------------------------------
     # measurement hooks used by bench.py (HIP events around the voxelize kernel on the launch stream)
+    def debug_option(self, name: str, value: int):
+        """Testing aid (mvx_debug_set_option): force code paths production sizes rarely reach."""
+        _lib.check(self._lib.mvx_debug_set_option(self._handle, name.encode(), int(value)))
+
     def set_profiling(self, enable: bool):
         _lib.check(self._lib.mvx_set_profiling(self._handle, 1 if enable else 0))
 

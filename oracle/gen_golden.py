@@ -15,6 +15,7 @@ Writes:
   tests/golden/transform_cases.npz   seeded random-transform cases (np.random.seed -> coords out)
   tests/golden/api_cases.npz     end-to-end Voxelizer.forward calls through the reference's public API
   tests/golden/dx_cases.npz      OpenDX dumps written by the reference's dx.py
+  tests/golden/dense_cases.npz   dense clusters (sums of hundreds of terms): full arrays
 """
 from __future__ import annotations
 
@@ -163,6 +164,39 @@ def gen_p64(molvoxel):
     store["index"] = np.array(json.dumps(index))
     np.savez_compressed(os.path.join(GOLD, "p64_cases.npz"), **store)
     print(f"p64_cases: {len(index)} cases")
+
+
+def gen_dense(molvoxel):
+    """Dense clusters: hundreds of in-radius atoms per voxel, so that float32 sums are large and the order of
+    summation (reference: BLAS sgemm, unspecified) matters. Full arrays from the reference; they pin the size of the
+    HIP-vs-reference error where it is largest (tests/tolerance.py states the rule the tests apply)."""
+    store, index = {}, []
+    rng = np.random.default_rng(8086)
+
+    def add(cid, D, density, sigma, radii_type, mode, xyz, chan, rad):
+        v = molvoxel.create_voxelizer(0.5, D, radii_type, density, "numpy", sigma=sigma)
+        out = v.forward(xyz, None, chan, rad)
+        store[f"{cid}/coords"], store[f"{cid}/out"] = xyz, out
+        if chan is not None:
+            store[f"{cid}/chan"] = chan
+        if not np.isscalar(rad):
+            store[f"{cid}/radii"] = rad
+        index.append(dict(id=cid, dimension=D, density=density, sigma=sigma, radii_type=radii_type, mode=mode,
+                          scalar_radius=float(rad) if np.isscalar(rad) else None, max=float(out.max())))
+        print(cid, out.shape, "max", float(out.max()))
+
+    xyz = rng.normal(scale=0.8, size=(3000, 3))
+    add("d0_cluster_features", 24, "gaussian", 0.5, "scalar", "features", xyz, rng.random((3000, 32)).astype(np.float32), 1.0)
+    add("d1_cluster_types", 24, "gaussian", 0.5, "scalar", "types", xyz, rng.integers(0, 3, 3000).astype(np.int16), 1.0)
+    add("d2_cluster_single_binary", 24, "binary", 0.5, "scalar", "single", xyz, None, 1.0)
+    W = 0.5 * 31
+    xyz2 = rng.uniform(-W / 2, W / 2, (2000, 3))
+    add("d3_uniform_r1.5_features", 32, "gaussian", 0.5, "scalar", "features", xyz2, rng.random((2000, 8)).astype(np.float32), 1.5)
+    add("d4_uniform_atomwise_features", 32, "gaussian", 1.0, "atom-wise", "features", xyz2,
+        rng.random((2000, 8)).astype(np.float32), rng.uniform(1.0, 2.0, 2000).astype(np.float32))
+    store["index"] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(GOLD, "dense_cases.npz"), **store)
+    print("dense_cases:", len(index))
 
 
 # ----------------------------------------------------------------------------- big cases
@@ -361,6 +395,8 @@ def main():
         gen_small(molvoxel)
     if not only or "p64" in only:
         gen_p64(molvoxel)
+    if not only or "dense" in only:
+        gen_dense(molvoxel)
     if not only or "big" in only:
         gen_big(molvoxel, pc)
     if not only or "transform" in only:

@@ -1,0 +1,119 @@
+"""Parity at the exact launch shapes that are benchmarked (bench.py, bench_configs.py).
+
+The headline number is one forward_batch of 256 cfg-2 molecules on device tensors (gridDim.y = 256, 1.02 M atoms);
+the ligand row is cfg-4 x 128 (ragged 40-60 atoms), the stress row cfg-5 x 4. Here those very calls are checked:
+first / middle / last molecule of each batch against the CPU oracle (membership identical + the one tolerance rule),
+molecule 0 against the reference's golden samples, and every other molecule by property: its slice of the batch grid
+equals the same molecule's single-call grid bit for bit (what the reference's own harness asserts,
+test/test_time_numpy.py:65-69, restated for batches).
+"""
+import numpy as np
+import pytest
+
+from tests import goldens
+from tests.tolerance import GAUSS_TOL, assert_gaussian
+
+pytestmark = pytest.mark.gpu
+
+Z_BIG, IDX_BIG = goldens.load("big_cases.npz")
+
+
+def _oracle(wl, i):
+    from oracle import c_oracle
+
+    return c_oracle.voxelize(wl.coords[i] - wl.centers[i].reshape(1, 3), wl.channels[i], wl.radii[i],
+                             resolution=wl.resolution, dimension=wl.dimension, radii_type=wl.radii_type,
+                             density=wl.density, sigma=wl.sigma, num_channels=wl.num_channels)
+
+
+def _batch_call(vox, wl, ids):
+    coords = np.concatenate([wl.coords[i] - wl.centers[i] for i in ids])
+    offsets = np.cumsum([0] + [wl.coords[i].shape[0] for i in ids]).astype(np.int64)
+    d_coords = vox.asarray(coords, "coords")
+    d_chan = vox.asarray(np.concatenate([wl.channels[i] for i in ids]), "features")
+    radii = wl.radii[ids[0]]
+    if not np.isscalar(radii):
+        radii = vox.asarray(np.concatenate([wl.radii[i] for i in ids]), "radii")
+    out = vox.get_empty_grid(wl.num_channels, batch_size=len(ids))
+    out.fill_(float("nan"))  # every voxel must be overwritten
+    got = vox.forward_batch(d_coords, offsets, None, d_chan, radii, out_grid=out)
+    assert got is out
+    return out, d_coords, d_chan, radii, offsets
+
+
+def _check_batch(mv, wl, ids, oracle_ids, single_ids):
+    import torch
+
+    vox = mv.create_voxelizer(wl.resolution, wl.dimension, wl.radii_type, wl.density, library="hip", sigma=wl.sigma)
+    out, d_coords, d_chan, radii, offsets = _batch_call(vox, wl, ids)
+    assert not torch.isnan(out).any()
+    for b in oracle_ids:
+        assert_gaussian(out[b].cpu().numpy(), _oracle(wl, ids[b]))
+    one = vox.get_empty_grid(wl.num_channels)
+    for b in single_ids:
+        lo, hi = int(offsets[b]), int(offsets[b + 1])
+        r = radii if np.isscalar(radii) else radii[lo:hi]
+        vox.forward_features(d_coords[lo:hi], None, d_chan[lo:hi], r, out_grid=one)
+        assert torch.equal(out[b], one), f"batch slice {b} differs from the single call"
+    return out
+
+
+def test_cfg2_x256_the_headline_launch():
+    """bench.py's step: 256 cfg-2 molecules (seeds 0, 1000, ...), device tensors, one forward_batch."""
+    import molvoxel_amd as mv
+    from molvoxel_amd import workloads as W
+
+    wl = W.cfg2(batch=256)
+    out = _check_batch(mv, wl, list(range(256)), oracle_ids=(0, 128, 255), single_ids=range(0, 256, 5))
+    # molecule 0 is the BASELINE seed-0 molecule: the reference's own samples
+    case = next(c for c in IDX_BIG if c["id"] == "cfg2_features_gaussian")
+    flat = out[0].reshape(-1).cpu().numpy()
+    idx, val = Z_BIG[f"{case['id']}/sample_idx"], Z_BIG[f"{case['id']}/sample_val"]
+    assert (np.abs(flat[idx] - val) <= GAUSS_TOL * np.maximum(1.0, np.abs(val))).all()
+    assert int(np.count_nonzero(flat)) == case["nonzero"]
+
+
+def test_cfg4_x128_ragged_ligands():
+    """cfg-4's per-GPU share: 128 ligands of 40-60 atoms, C = 16, one forward_batch."""
+    import molvoxel_amd as mv
+    from molvoxel_amd import workloads as W
+
+    wl = W.cfg4(batch=128)
+    out = _check_batch(mv, wl, list(range(128)), oracle_ids=(0, 64, 127), single_ids=range(128))
+    for k in range(8):  # the reference's goldens for the first 8 ligands (same seed-4 stream)
+        case = next(c for c in IDX_BIG if c["id"] == f"cfg4_features_gaussian_m{k}")
+        flat = out[k].reshape(-1).cpu().numpy()
+        idx, val = Z_BIG[f"{case['id']}/sample_idx"], Z_BIG[f"{case['id']}/sample_val"]
+        assert np.abs(flat[idx] - val).max() <= GAUSS_TOL
+        assert int(np.count_nonzero(flat)) == case["nonzero"]
+
+
+def test_cfg5_x4_high_resolution():
+    """cfg-5 x 4: 128^3, sigma 1.0, atom-wise radii, N = 10 000, C = 32 (1.07 GB of grids)."""
+    import molvoxel_amd as mv
+    from molvoxel_amd import workloads as W
+
+    wl = W.cfg5(batch=4)
+    out = _check_batch(mv, wl, [0, 1, 2, 3], oracle_ids=(0, 3), single_ids=(0, 1, 2, 3))
+    case = next(c for c in IDX_BIG if c["id"] == "cfg5_features_gaussian")
+    flat = out[0].reshape(-1).cpu().numpy()
+    idx, val = Z_BIG[f"{case['id']}/sample_idx"], Z_BIG[f"{case['id']}/sample_val"]
+    assert (np.abs(flat[idx] - val) <= GAUSS_TOL * np.maximum(1.0, np.abs(val))).all()
+    assert int(np.count_nonzero(flat)) == case["nonzero"]
+
+
+def test_bench_spot_check_helper():
+    """The post-timing spot check bench.py runs (outside the timed region) passes on a correct grid and fails on a
+    corrupted one."""
+    import molvoxel_amd as mv
+    import bench
+    from molvoxel_amd import workloads as W
+
+    wl = W.cfg2(batch=3)
+    vox = mv.create_voxelizer(0.5, 64, "scalar", "gaussian", library="hip")
+    out, *_ = _batch_call(vox, wl, [0, 1, 2])
+    coords = [wl.coords[i] for i in range(3)]
+    feats = [wl.channels[i] for i in range(3)]
+    assert bench.parity_spot(out, coords, feats, picks=(0, 2)) == "ok"
+    out[2, 5, 10, 10, 10] += 1.0
+    assert bench.parity_spot(out, coords, feats, picks=(0, 2)).startswith("FAIL")

@@ -1,0 +1,49 @@
+"""Per-molecule `forward()` calls of one BASELINE configuration, for rocprofv3 --kernel-trace --stats and host timing.
+
+    python3 tools/single_calls.py cfg2 [calls]      (cfg1 | cfg2 | cfg3 | cfg5 | harness)
+Prints host-side us per call (back-to-back, drained at the end).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import molvoxel_amd
+from molvoxel_amd import workloads as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+name = sys.argv[1]
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+pc = np.load(os.path.join(ROOT, "tests", "golden", "pointcloud_10gs.npz"))
+tr, rot = 0.0, False
+if name == "harness":  # test/test_time_numpy.py: 10gs complex, 48^3, C = 10, random transform per call
+    import bench_configs
+
+    xyz, center, types, feats = bench_configs.harness_inputs()
+    vox = molvoxel_amd.create_voxelizer(0.5, 48, library="hip")
+    coords, cen = vox.asarray(xyz, "coords"), vox.asarray(center, "center")
+    chan, radii, C_ = vox.asarray(feats, "features"), 1.0, 10
+    tr, rot = 0.5, True
+else:
+    wl = {"cfg1": lambda: W.cfg1(pc["ligand_xyz"], pc["ligand_feat5"]), "cfg2": W.cfg2, "cfg3": W.cfg3, "cfg5": W.cfg5}[name]()
+    vox = molvoxel_amd.create_voxelizer(wl.resolution, wl.dimension, wl.radii_type, wl.density, library="hip",
+                                        **({"sigma": wl.sigma} if wl.density == "gaussian" else {}))
+    coords = vox.asarray(wl.coords[0] - wl.centers[0], "coords")
+    cen = None
+    chan = vox.asarray(wl.channels[0], wl.mode)
+    radii = wl.radii[0] if np.isscalar(wl.radii[0]) else vox.asarray(wl.radii[0], "radii")
+    C_ = wl.num_channels
+grid = vox.get_empty_grid(C_)
+for _ in range(20):
+    vox.forward(coords, cen, chan, radii, tr, rot, out_grid=grid)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(calls):
+    vox.forward(coords, cen, chan, radii, tr, rot, out_grid=grid)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"{name}: host {1e6 * (t1 - t0) / calls:.1f} us/call, with drain {1e6 * (t2 - t0) / calls:.1f} us/call over {calls} calls")
