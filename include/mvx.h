@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MVX_VERSION 110 /* 0.1.1: mvx_config.precision, mvx_real */
+#define MVX_VERSION 120 /* 0.1.2: mvx_xform.center_ptr, stream hand-over, unaligned out, mvx_debug_set_option */
 
 typedef enum mvx_status {
     MVX_OK = 0,
@@ -67,7 +67,9 @@ enum mvx_xform_flags {
     MVX_XF_CENTER = 1,    /* p = p - center first */
     MVX_XF_ROTATE = 2,    /* p = q * p * q^-1 */
     MVX_XF_TRANSLATE = 4, /* p = p + trans (twice when MVX_XF_ROTATE is also set, as the reference does) */
-    MVX_XF_RECENTER = 8   /* p = p + center after the rotation (do_transform with a center, numpy/transform.py:51-54) */
+    MVX_XF_RECENTER = 8,  /* p = p + center after the rotation (do_transform with a center, numpy/transform.py:51-54) */
+    MVX_XF_CENTER_PTR = 16 /* the centre is read from center_ptr (3 doubles in the memory `in_kind` names) instead of
+                              center[]: a device-resident `center` tensor never has to visit the host */
 };
 
 /*
@@ -103,6 +105,7 @@ typedef struct mvx_xform {
     double quat[4];   /* (q0, q1, q2, q3) as returned by random_quaternion, _quaternion.py:13-21 */
     float trans[3];   /* float32 like numpy/transform.py:76 */
     uint32_t flags;   /* enum mvx_xform_flags */
+    const double *center_ptr; /* MVX_XF_CENTER_PTR: where the centre lives (same memory kind as coords) */
 } mvx_xform;
 
 typedef struct mvx_handle mvx_handle;

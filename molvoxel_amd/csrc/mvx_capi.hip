@@ -49,6 +49,10 @@ struct PinnedSlot {
 };
 
 constexpr int NSLOTS = 4;
+// voxelize_direct_kernel instead of the binned pipeline (run()): one molecule of up to this many atoms ...
+constexpr int64_t DIRECT_MAX_ATOMS_SINGLE = 8192;
+// ... or a batch whose largest molecule has at most this many (one scan round per workgroup)
+constexpr int64_t DIRECT_MAX_ATOMS_BATCH = 256;
 
 } // namespace
 
@@ -81,6 +85,9 @@ struct mvx_handle {
     hipStream_t side = nullptr;
     hipEvent_t ev_in = nullptr;
     std::vector<hipEvent_t> ev_pre;
+    // -1: the library picks (run()); 0: always the binned three-launch pipeline; 1: always voxelize_direct_kernel
+    // (where it applies: float32 grids). Set by mvx_debug_set_option("direct", v) in tests and A/B runs.
+    int direct_mode = -1;
     int store_kind = 1; // nt: measured 0.69 -> 0.54 ms on cfg-2 (output lines do not displace the re-read inputs in L2)
 };
 
@@ -148,6 +155,9 @@ void make_geom(mvx_handle *h) {
     g.D = c.dimension;
     g.bd = c.blockdim > 0 ? c.blockdim : 8;                        // numpy/voxelizer.py:38
     g.nb = (g.D + g.bd - 1) / g.bd;                                // numpy/voxelizer.py:44
+    g.pad = 0;
+    g.inv_res = 1.0 / g.res;
+    g.inv_pitch = 1.0 / ((double)g.bd * g.res);
     h->g = g;
     h->sigma32 = (float)c.sigma;
 }
@@ -230,6 +240,17 @@ struct DeviceInputs {
     PinnedSlot *slot = nullptr; // holds the host copies until `done` fires
 };
 
+// With host-resident inputs a centre given by pointer (MVX_XF_CENTER_PTR) is a host pointer: fold it into center[].
+void resolve_host_centers(mvx_xform *xf, int n) {
+    for (int i = 0; i < n; ++i) {
+        if (xf[i].flags & MVX_XF_CENTER_PTR) {
+            if (xf[i].center_ptr) std::memcpy(xf[i].center, xf[i].center_ptr, 3 * sizeof(double));
+            xf[i].flags &= ~(uint32_t)MVX_XF_CENTER_PTR;
+            xf[i].center_ptr = nullptr;
+        }
+    }
+}
+
 // Host-resident arrays go through one pinned slot (a single memcpy each, then async H2D on the caller's stream);
 // device-resident arrays are used where they are. Offsets and transforms always come from the host.
 int stage_inputs(mvx_handle *h, const RunArgs &r, int64_t total, size_t esz, hipStream_t s, DeviceInputs &in) {
@@ -257,7 +278,10 @@ int stage_inputs(mvx_handle *h, const RunArgs &r, int64_t total, size_t esz, hip
                            std::memcmp(h->meta_last.data(), r.offsets, meta_used) == 0;
     if (!meta_same) {
         std::memcpy(pin, r.offsets, meta_used);
-        if (r.xforms) std::memcpy(pin + off_bytes, r.xforms, (size_t)r.B * sizeof(mvx_xform));
+        if (r.xforms) {
+            std::memcpy(pin + off_bytes, r.xforms, (size_t)r.B * sizeof(mvx_xform));
+            if (host_in) resolve_host_centers(reinterpret_cast<mvx_xform *>(pin + off_bytes), r.B);
+        }
         HIP_TRY(hipMemcpyAsync(h->meta.p, pin, off_bytes + xf_bytes, hipMemcpyHostToDevice, s));
         h->meta_last.assign(reinterpret_cast<const char *>(r.offsets), reinterpret_cast<const char *>(r.offsets) + meta_used);
         h->meta_valid = !r.xforms; // (a later call on another stream waits for this stream first: adopt_stream)
@@ -338,8 +362,27 @@ int run(mvx_handle *h, const RunArgs &r) {
     const size_t esz = f64 ? sizeof(double) : sizeof(float); // element size of features, radii and the grid
     const size_t out_bytes = (size_t)r.B * r.C * D * D * D * esz;
 
+    // channels per workgroup (register accumulators per lane); more channels -> several channel chunks
+    const int ct = pick_ct(std::min(r.C, f64 ? std::min(h->max_ct, 16) : h->max_ct)); // float64 rows: <= 16 channels
+    const int ncc = (r.C + ct - 1) / ct;
+    const SlabPlan sp = plan_slabs(h);
+    // One launch for the whole call (voxelize_direct_kernel) when the per-workgroup atom scan is cheap next to the
+    // slab's stores: per-molecule forward() calls, and batches of small molecules. Bigger jobs amortise the binning
+    // pre-pass and take the three-launch pipeline.
+    bool direct = false;
+    if (!f64 && sp.NW <= 8 && (long long)r.B * ncc <= 65535) {
+        if (h->direct_mode >= 0) direct = h->direct_mode == 1;
+        else direct = (r.B == 1 && total <= DIRECT_MAX_ATOMS_SINGLE) || max_atoms <= DIRECT_MAX_ATOMS_BATCH;
+    }
+
     DeviceInputs in;
-    if ((rc = stage_inputs(h, r, total, esz, s, in))) return rc;
+    if (direct && r.B == 1 && r.in_kind == MVX_DEVICE) { // nothing to stage: extent and transform travel by value
+        in.coords = r.coords;
+        in.channels = r.channels;
+        in.radii = r.radii;
+    } else if ((rc = stage_inputs(h, r, total, esz, s, in))) {
+        return rc;
+    }
     void *d_out = r.out;
     if (r.out_kind == MVX_HOST) {
         if ((rc = ensure(h->out_stage, out_bytes))) return rc;
@@ -348,32 +391,30 @@ int run(mvx_handle *h, const RunArgs &r) {
 
     // ---- workspace --------------------------------------------------------------------------------
     const size_t n_alloc = (size_t)std::max<int64_t>(total, 1);
-    // channels per workgroup (register accumulators per lane); more channels -> several channel chunks
-    const int ct = pick_ct(std::min(r.C, f64 ? std::min(h->max_ct, 16) : h->max_ct)); // float64 rows: <= 16 channels
-    const int ncc = (r.C + ct - 1) / ct;
     const int Cpad = (ncc > 1) ? ncc * ct : (ct < 4 ? 4 : ct); // channel weights per atom, zero padded
     // feature rows that already are Cpad wide are read in place; anything else (one-hot types, 1, padding) is packed
     const bool direct_w = (r.mode == MODE_FEATURES && r.C == Cpad);
-    const SlabPlan sp = plan_slabs(h);
     const size_t nslabs = (size_t)r.B * sp.per_molecule();
     if (nslabs * (size_t)ncc + 1 > (size_t)0x7fffffff) return fail(MVX_ERR_INVALID, "batch too large for one call");
-    if ((rc = ensure(h->rec, n_alloc * sizeof(AtomRec)))) return rc;
-    if (!direct_w && (rc = ensure(h->wbuf, n_alloc * (size_t)Cpad * esz))) return rc;
-    if ((rc = ensure(h->xp, n_alloc * sizeof(uint2)))) return rc;
-    // x-lists: packed regions, (sum(N) + 2*B) * nsx entries; slab lines: primary + extension entries per slab
-    if ((rc = ensure(h->xlist, ((size_t)total + 2 * (size_t)r.B) * sp.nsx * sizeof(uint2)))) return rc;
-    if ((rc = ensure(h->slist, nslabs * (SLAB_LINE_ENTRIES + SLAB_EXT_ENTRIES) * sizeof(uint2)))) return rc;
-    if ((rc = ensure(h->overflow, (nslabs * (size_t)ncc + 1) * sizeof(int)))) return rc;
+    if (!direct) {
+        if ((rc = ensure(h->rec, n_alloc * sizeof(AtomRec)))) return rc;
+        if (!direct_w && (rc = ensure(h->wbuf, n_alloc * (size_t)Cpad * esz))) return rc;
+        if ((rc = ensure(h->xp, n_alloc * sizeof(uint2)))) return rc;
+        // x-lists: packed regions, (sum(N) + 2*B) * nsx entries; slab lines: primary + extension entries per slab
+        if ((rc = ensure(h->xlist, ((size_t)total + 2 * (size_t)r.B) * sp.nsx * sizeof(uint2)))) return rc;
+        if ((rc = ensure(h->slist, nslabs * (SLAB_LINE_ENTRIES + SLAB_EXT_ENTRIES) * sizeof(uint2)))) return rc;
+        if ((rc = ensure(h->overflow, (nslabs * (size_t)ncc + 1) * sizeof(int)))) return rc;
+    }
     uint2 *d_xlist = reinterpret_cast<uint2 *>(h->xlist.p);
     uint2 *d_slist = reinterpret_cast<uint2 *>(h->slist.p);
-    uint2 *d_slist_ext = d_slist + nslabs * SLAB_LINE_ENTRIES; // extension lines live behind the primary lines
+    uint2 *d_slist_ext = d_slist ? d_slist + nslabs * SLAB_LINE_ENTRIES : nullptr; // extension lines live behind the primary lines
 
     const bool gauss = (h->cfg.density == MVX_GAUSSIAN);
     const bool chanwise = (r.radii_type == MVX_RADII_CHANNEL && r.mode == MODE_FEATURES);
     void *d_rmax = nullptr;
     double *d_Tc = nullptr;
     float *d_kc = nullptr;
-    if (chanwise) {
+    if (chanwise && !direct) {
         const size_t tc_off = 16, kc_off = tc_off + align_up((size_t)r.C * sizeof(double), 16);
         if ((rc = ensure(h->aux, kc_off + (size_t)r.C * sizeof(float)))) return rc;
         d_rmax = h->aux.p;
@@ -448,6 +489,38 @@ int run(mvx_handle *h, const RunArgs &r) {
     // a sub-tile lies inside one reference block when its edges divide blockdim (or there is a single block):
     // the block cull is then wave-uniform and already folded into the candidate ranges.
     const bool lane_range = !(g.nb == 1 || (g.bd % SUBX == 0 && g.bd % SUBY == 0 && g.bd % SUBZ == 0));
+
+    if (direct) {
+        DirectArgs da;
+        da.pa = pa;
+        da.pa.rec = nullptr;
+        da.pa.wbuf = nullptr;
+        da.pa.xp = nullptr;
+        da.pa.chan_aux = nullptr;
+        da.N = total;
+        std::memset(&da.xf, 0, sizeof(da.xf));
+        if (r.B == 1) { // one molecule: extent and transform by value, no metadata on the device
+            da.pa.offsets = nullptr;
+            da.pa.xforms = nullptr;
+            if (r.xforms) {
+                da.xf = r.xforms[0];
+                if (r.in_kind == MVX_HOST) resolve_host_centers(&da.xf, 1);
+            }
+        }
+        if ((rc = timed_launch(h, s, [&] {
+                 return launch_voxelize_direct(da, va.p, static_cast<float *>(d_out), ct, gauss, chanwise, lane_range, s);
+             })))
+            return rc;
+        if (in.slot) {
+            HIP_TRY(hipEventRecord(in.slot->done, s));
+            in.slot->in_flight = true;
+        }
+        if (r.out_kind == MVX_HOST) {
+            HIP_TRY(hipMemcpyAsync(r.out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        return MVX_OK;
+    }
 
     // ---- launches: molecules in chunks (gridDim.y limit; optionally pre-pass on the side stream, one chunk ahead) ----
     const int max_mol = 65535 / ncc;
@@ -663,6 +736,7 @@ int mvx_transform_coords(mvx_handle *h, const double *coords, int64_t N, const m
     if ((rc = ensure(h->meta, xf_bytes))) return rc;
     h->meta_valid = false; // the buffer now holds a transform, not batch offsets
     std::memcpy(slot->p, xform, sizeof(mvx_xform));
+    if (host_in) resolve_host_centers(reinterpret_cast<mvx_xform *>(slot->p), 1);
     HIP_TRY(hipMemcpyAsync(h->meta.p, slot->p, xf_bytes, hipMemcpyHostToDevice, s));
     const double *d_in = coords;
     if (host_in) {
@@ -739,6 +813,7 @@ int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
     const std::string n(name);
     if (n == "chunks") h->pipeline = std::max(1, std::min(16, (int)value));
     else if (n == "max_ct") h->max_ct = std::max(1, std::min(32, (int)value));
+    else if (n == "direct") h->direct_mode = value < 0 ? -1 : (value ? 1 : 0);
     else return fail(MVX_ERR_INVALID, "unknown option: " + n);
     return MVX_OK;
 }

@@ -39,6 +39,9 @@ struct Geom {
     int32_t D;
     int32_t bd;  // reference blockdim (cull emulation)
     int32_t nb;  // ceil(D / bd)
+    int32_t pad;
+    double inv_res;   // 1.0 / res
+    double inv_pitch; // 1.0 / (bd * res)
 };
 
 struct PrepArgs {
@@ -82,6 +85,14 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
     double sigma;          // float64 grids: the Gaussian sigma as the reference holds it (python float)
 };
 
+// voxelize_direct_kernel: the atoms as the caller passed them (PrepArgs without workspace pointers) plus, for a
+// single molecule, its extent and transform by value (no metadata upload).
+struct DirectArgs {
+    PrepArgs pa;   // rec / wbuf / xp / chan_aux unused; offsets / xforms: device arrays, or null for one molecule
+    mvx_xform xf;  // the transform when pa.xforms is null (flags == 0: none)
+    int64_t N;     // atoms of the only molecule when pa.offsets is null
+};
+
 struct VoxArgs {
     const unsigned *rec;   // per-atom records (16 words each)
     const unsigned *w;     // channel weights: the caller's feature rows or prep's packed copy (p.w_stride apart)
@@ -113,6 +124,9 @@ hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss,
 hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
 // process the overflow list of all launches since it was zeroed (one launch per call)
 hipError_t launch_voxelize_dense(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
+// the whole call in one launch (float32 grids, NW <= 8): no workspace, no pre-pass
+hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, bool chanwise,
+                                  bool lane_range, hipStream_t s);
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW);
 int32_t voxelize_dcap(int32_t ct, int32_t NW);
 

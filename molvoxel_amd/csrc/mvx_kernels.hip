@@ -70,10 +70,16 @@ __device__ __forceinline__ float gauss_coeff(float r32, float sigma32) {
 
 // do_transform in the reference's operation order (numpy/transform.py:44-60, _quaternion.py:24-50).
 __device__ void apply_xform(const mvx_xform &xf, double &x, double &y, double &z) {
+    double c0 = xf.center[0], c1 = xf.center[1], c2 = xf.center[2];
+    if (xf.flags & MVX_XF_CENTER_PTR) { // a device-resident centre (the host never saw its value)
+        c0 = xf.center_ptr[0];
+        c1 = xf.center_ptr[1];
+        c2 = xf.center_ptr[2];
+    }
     if (xf.flags & MVX_XF_CENTER) {
-        x = x - xf.center[0];
-        y = y - xf.center[1];
-        z = z - xf.center[2];
+        x = x - c0;
+        y = y - c1;
+        z = z - c2;
     }
     const double t0 = (double)xf.trans[0], t1 = (double)xf.trans[1], t2 = (double)xf.trans[2];
     if (xf.flags & MVX_XF_ROTATE) {
@@ -90,9 +96,9 @@ __device__ void apply_xform(const mvx_xform &xf, double &x, double &y, double &z
         y = ((a0 * i2 - a1 * i3) + a2 * i0) + a3 * i1;
         z = ((a0 * i3 + a1 * i2) - a2 * i1) + a3 * i0;
         if (xf.flags & MVX_XF_RECENTER) { // `coords += center` (numpy/transform.py:53)
-            x += xf.center[0];
-            y += xf.center[1];
-            z += xf.center[2];
+            x += c0;
+            y += c1;
+            z += c2;
         }
         if (xf.flags & MVX_XF_TRANSLATE) { // `coords += translation` inside the rotation branch
             x += t0;
@@ -168,14 +174,14 @@ __device__ __forceinline__ void block_interval(const Geom &g, double p, double r
     const double hres = g.res / 2.0;
     const int last = g.nb - 1; // counts range over [0, nb-1]
     auto bound = [&](int m) { return ((double)((m + 1) * g.bd) * g.res - g.half) + hres; }; // numpy/voxelizer.py:55
-    const double pitch = (double)g.bd * g.res;
+    const double inv_pitch = g.inv_pitch; // 1 / (bd * res): the estimates below need not be exact
     auto clampi = [&](double v) { return v < 0.0 ? 0 : (v > (double)last ? last : (int)v); };
     // bhi = #{m < nb-1 : p > bound(m) - r}
-    int bhi = clampi(floor((p + r + g.half - hres) / pitch));
+    int bhi = clampi(floor((p + r + g.half - hres) * inv_pitch));
     while (bhi < last && p > bound(bhi) - r) ++bhi;
     while (bhi > 0 && !(p > bound(bhi - 1) - r)) --bhi;
     // blo = #{m < nb-1 : !(p < bound(m) + r)}
-    int blo = clampi(floor((p - r + g.half - hres) / pitch));
+    int blo = clampi(floor((p - r + g.half - hres) * inv_pitch));
     while (blo < last && !(p < bound(blo) + r)) ++blo;
     while (blo > 0 && (p < bound(blo - 1) + r)) --blo;
     vlo = blo * g.bd;
@@ -187,31 +193,14 @@ __device__ __forceinline__ void block_interval(const Geom &g, double p, double r
 constexpr uint32_t EMPTY_RANGE = 0x0000ffffu;
 constexpr uint32_t EMPTY_ENTRY = 0x00ff00ffu; // packed y/z slab ranges: y lo = z lo = 255, hi = 0: matches no slab
 
-// Packs the channel weights too when the voxelize kernels cannot read the caller's feature rows as they are
-// (one-hot type / 1 / zero padded features): the block copies the weights of its 256 atoms cooperatively.
-__global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
-    const int64_t a = A.first + (int64_t)blockIdx.x * 256 + threadIdx.x;
+// Everything the path knows about one atom once its position p (after centring / transform) is fixed: the culls of
+// rule steps 1-2 folded into admitted voxel ranges, the membership threshold T, the gaussian coefficient k. Shared by
+// prep_kernel (one thread per atom, records to memory) and voxelize_direct_kernel (one lane per candidate, records
+// straight into LDS). rmax32 / rmax64: max channel radius (RAD_CHANNEL_FEATURES only). Returns false when no voxel
+// can receive a contribution (ranges then are EMPTY_RANGE).
+__device__ __forceinline__ bool prep_atom(const PrepArgs &A, int64_t a, const double (&p)[3], float rmax32, double rmax64,
+                                          AtomRec &R, uint32_t (&rng)[3]) {
     const bool f64 = (A.precision == 64);
-    if (A.wbuf) {
-        const int64_t first = A.first + (int64_t)blockIdx.x * 256;
-        const int nat = (int)((A.total - first) < 256 ? (A.total - first) : 256);
-        for (int i = threadIdx.x; i < nat * A.Cpad; i += 256) {
-            const int al = i / A.Cpad, c = i - al * A.Cpad;
-            double f = 0.0;
-            if (c < A.C) {
-                if (A.mode == MODE_FEATURES)
-                    f = f64 ? static_cast<const double *>(A.features)[(first + al) * A.C + c]
-                            : (double)static_cast<const float *>(A.features)[(first + al) * A.C + c];
-                else if (A.mode == MODE_TYPES) f = (A.types[first + al] == c) ? 1.0 : 0.0;
-                else f = 1.0;
-            }
-            if (f64) static_cast<double *>(A.wbuf)[first * A.Cpad + i] = f;
-            else static_cast<float *>(A.wbuf)[first * A.Cpad + i] = (float)f;
-        }
-    }
-    if (a >= A.total) return;
-    double p[3] = {A.coords[3 * a], A.coords[3 * a + 1], A.coords[3 * a + 2]};
-    if (A.xforms) apply_xform(A.xforms[find_molecule(A.offsets, A.B, a)], p[0], p[1], p[2]); // (8 dependent loads: only when needed)
 
     const Geom g = A.g;
     const double ub = g.half, lb = -1 * g.half;
@@ -234,13 +223,13 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
     } else if (A.radii_src == RAD_CHANNEL_FEATURES) {
         double lo, hi;
         if (f64) { // np.float64 scalar: plain float64 arithmetic
-            r64 = static_cast<const double *>(A.chan_aux)[0];
+            r64 = rmax64;
             r32 = (float)r64;
             rc = rwin = r64;
             lo = lb - r64;
             hi = ub + r64;
         } else {
-            const float rmax = static_cast<const float *>(A.chan_aux)[0];
+            const float rmax = rmax32;
             r32 = rmax;
             rc = rwin = (double)rmax;
             // np.float32 scalar: (python float -/+ float32) is evaluated in float32 (NEP 50), numpy/voxelizer.py:138
@@ -261,7 +250,6 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
         for (int i = 0; i < 3; ++i) keep = keep && (p[i] + rc > lb) && (p[i] - rc < ub); // numpy/voxelizer.py:491-492
     }
 
-    AtomRec R;
     R.px = p[0];
     R.py = p[1];
     R.pz = p[2];
@@ -276,14 +264,14 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
     R.pad[0] = R.pad[1] = R.pad[2] = 0;
     keep = keep && (R.T >= 0.0);
 
-    uint32_t rng[3] = {EMPTY_RANGE, EMPTY_RANGE, EMPTY_RANGE};
+    rng[0] = rng[1] = rng[2] = EMPTY_RANGE;
     if (keep) {
         // Voxels that can pass |p - g_i| <= r are i in [ceil((p - r - g0)/res), floor((p + r - g0)/res)]; the
         // radius is widened by 1e-6 relative (fp64 rounding of this estimate is ~1e-15) so the window is a
         // superset of the membership set; membership itself is decided per voxel with the exact threshold.
         // (a multiplication by 1/res is off by ~1e-13 voxels here, the widening is >= 1e-9: still a superset)
         const double rr = rwin * 1.000001 + 1e-9;
-        const double inv_res = 1.0 / g.res;
+        const double inv_res = g.inv_res; // 1.0 / res, rounded once on the host
         for (int i = 0; i < 3; ++i) {
             double flo = ceil((p[i] - rr + g.half) * inv_res);
             double fhi = floor((p[i] + rr + g.half) * inv_res);
@@ -311,6 +299,43 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
     R.xr = rng[0];
     R.yr = rng[1];
     R.zr = rng[2];
+    return keep;
+}
+
+// Packs the channel weights too when the voxelize kernels cannot read the caller's feature rows as they are
+// (one-hot type / 1 / zero padded features): the block copies the weights of its 256 atoms cooperatively.
+__global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
+    const int64_t a = A.first + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool f64 = (A.precision == 64);
+    if (A.wbuf) {
+        const int64_t first = A.first + (int64_t)blockIdx.x * 256;
+        const int nat = (int)((A.total - first) < 256 ? (A.total - first) : 256);
+        for (int i = threadIdx.x; i < nat * A.Cpad; i += 256) {
+            const int al = i / A.Cpad, c = i - al * A.Cpad;
+            double f = 0.0;
+            if (c < A.C) {
+                if (A.mode == MODE_FEATURES)
+                    f = f64 ? static_cast<const double *>(A.features)[(first + al) * A.C + c]
+                            : (double)static_cast<const float *>(A.features)[(first + al) * A.C + c];
+                else if (A.mode == MODE_TYPES) f = (A.types[first + al] == c) ? 1.0 : 0.0;
+                else f = 1.0;
+            }
+            if (f64) static_cast<double *>(A.wbuf)[first * A.Cpad + i] = f;
+            else static_cast<float *>(A.wbuf)[first * A.Cpad + i] = (float)f;
+        }
+    }
+    if (a >= A.total) return;
+    double p[3] = {A.coords[3 * a], A.coords[3 * a + 1], A.coords[3 * a + 2]};
+    if (A.xforms) apply_xform(A.xforms[find_molecule(A.offsets, A.B, a)], p[0], p[1], p[2]); // (8 dependent loads: only when needed)
+    float rmax32 = 0.0f;
+    double rmax64 = 0.0;
+    if (A.radii_src == RAD_CHANNEL_FEATURES) {
+        if (f64) rmax64 = static_cast<const double *>(A.chan_aux)[0];
+        else rmax32 = static_cast<const float *>(A.chan_aux)[0];
+    }
+    AtomRec R;
+    uint32_t rng[3];
+    const bool keep = prep_atom(A, a, p, rmax32, rmax64, R, rng);
     {   // non-temporal: records are not re-read by this XCD; kept out of L2 they cost the voxelize kernel 2.4 % less
         typedef unsigned u4v __attribute__((ext_vector_type(4)));
         const u4v *src = reinterpret_cast<const u4v *>(&R);
@@ -1074,6 +1099,261 @@ __global__ void __launch_bounds__(1024)
 }
 
 // ------------------------------------------------------------------------------------------------
+// voxelize_direct_kernel: the whole call in ONE launch (per-molecule forward() calls, small batches)
+// ------------------------------------------------------------------------------------------------
+// The reference's unit of work is one molecule per forward() call (test/test_time_numpy.py:11-15). For such calls the
+// three-launch pipeline above (prep -> xbin -> voxelize, + an H2D copy of the transform) is all latency: 25-40 us of
+// launches and boundaries around 5-12 us of voxelize work. This kernel needs no workspace and no pre-pass:
+//   grid = (slab, molecule * ncc + channel chunk) as voxelize_kernel. Per workgroup:
+//   A. scan: wave w reads atoms [w*512, (w+1)*512) of the current 512*NW-atom segment straight from the caller's
+//      coords (transform applied in flight), tests the atom's conservative radius window against the slab's box
+//      (a superset of what prep_atom admits) and appends the survivors, by ballot + prefix, to its own region of an
+//      LDS list; one barrier. Regions in wave order = candidates IN ATOM ORDER (so sums are bit-identical to the
+//      binned path's);
+//   B. rounds of up to 64 candidates: lane u < 8 of wave w runs prep_atom (the same exact culls / threshold code the
+//      prep kernel runs) for slot w + u*NW and writes the 64-B record straight into the LDS row, while the wave's
+//      other lanes fetch the slot's channel weights from the caller's feature rows (or build the one-hot / unit row
+//      of forward_types / forward_single); the slab-level x / y / z-sub-tile range filters of the binning pass are
+//      applied here; one barrier; then the unchanged walk (Ops::accumulate) and write-out (Ops::write).
+//   Any number of candidates and atoms works (rounds, segments); there is no overflow list and no dense kernel.
+// LDS map: u16 list[NW*512] | int wcnt[16] | u32 pk[64] | double Tc[32] | float kc[32] | union { rows ; tile }.
+constexpr int SEGW = 512;            // atoms one wave scans per segment
+constexpr int SEG_ROUNDS = SEGW / 64;
+constexpr int DIRECT_HDR_BYTES = 64 + 256 + 32 * 8 + 32 * 4; // wcnt + pk + Tc + kc
+
+size_t direct_lds_bytes(int32_t ct, int32_t NW) { return (size_t)NW * SEGW * 2 + DIRECT_HDR_BYTES + voxelize_lds_bytes(ct, NW); }
+
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
+__global__ void __launch_bounds__(MAXT, 4)
+    voxelize_direct_kernel(const DirectArgs A, float *__restrict__ out, const VoxParams P) {
+    typedef OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE> Ops;
+    constexpr int SW = Ops::SW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = P.NW;
+    unsigned short *list = reinterpret_cast<unsigned short *>(smem);
+    int *wcnt = reinterpret_cast<int *>(smem + (size_t)NW * SEGW * 2);
+    unsigned *pk = reinterpret_cast<unsigned *>(wcnt + 16);
+    double *Tc_s = reinterpret_cast<double *>(pk + 64);
+    float *kc_s = reinterpret_cast<float *>(Tc_s + 32);
+    unsigned *un = reinterpret_cast<unsigned *>(kc_s + 32);
+
+    const unsigned t = blockIdx.x;
+    int b = (int)blockIdx.y, cc = 0;
+    if (P.ncc > 1) {
+        b = (int)blockIdx.y / P.ncc;
+        cc = (int)blockIdx.y - b * P.ncc;
+    }
+    int sx, sy, zc;
+    decode_slab(t, P, sx, sy, zc);
+    const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
+    const int zt_lo = zc * NW, zt_hi = zt_lo + NW - 1;
+    const LaneCtx L = make_lane_ctx(lane, wave, x0, y0, z0, zt_lo, cc * CT, P);
+    const PrepArgs &pa = A.pa;
+    const int C = pa.C;
+
+    int64_t a0 = 0, a1 = A.N;
+    if (pa.offsets) {
+        a0 = pa.offsets[b];
+        a1 = pa.offsets[b + 1];
+    }
+    mvx_xform xf = A.xf;
+    if (pa.xforms) xf = pa.xforms[b];
+    const bool has_xf = xf.flags != 0;
+
+    // channel-wise features: per-channel thresholds / coefficients of this chunk and max(radii), as chan_aux_kernel
+    float rmax32 = 0.0f;
+    if constexpr (CHANWISE) {
+        const float *cr = static_cast<const float *>(pa.radii);
+        if (tid < CT) {
+            const int ch = (L.cbase + tid < C) ? L.cbase + tid : C - 1;
+            const float r = cr[ch];
+            Tc_s[tid] = d2_threshold(r);
+            kc_s[tid] = GAUSS ? gauss_coeff(r, pa.sigma32) : 0.0f;
+        }
+        float m = cr[0];
+        for (int c = lane; c < C; c += 64) m = cr[c] > m ? cr[c] : m;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_xor(m, o, 64);
+            m = other > m ? other : m;
+        }
+        rmax32 = m;
+    }
+
+    // the slab's box, widened per atom by its radius window (superset of prep_atom's admitted ranges)
+    const int xh = (x0 + SUBX - 1 < P.D - 1) ? x0 + SUBX - 1 : P.D - 1;
+    const int yh = (y0 + SUBY - 1 < P.D - 1) ? y0 + SUBY - 1 : P.D - 1;
+    const int zh = (z0 + SUBZ * NW - 1 < P.D - 1) ? z0 + SUBZ * NW - 1 : P.D - 1;
+    const double slack = 1e-6 * P.res;
+    const double bx0 = (double)x0 * P.res - P.half - slack, bx1 = (double)xh * P.res - P.half + slack;
+    const double by0 = (double)y0 * P.res - P.half - slack, by1 = (double)yh * P.res - P.half + slack;
+    const double bz0 = (double)z0 * P.res - P.half - slack, bz1 = (double)zh * P.res - P.half + slack;
+
+    const int RW = 8 * NW < 64 ? 8 * NW : 64; // candidate rows per round
+    const int64_t SEGN = (int64_t)NW * SEGW;
+
+    // ---- A. scan of one segment: survivors of wave w -> list[w*SEGW ...], counts -> wcnt; returns their number ----
+    // (rolled, the next round's loads issued before this round's arithmetic; regions in wave order = atom order, so
+    // candidate j of the segment is entry j - base[w] of the wave w whose prefix interval holds j: no second pass)
+    auto scan = [&](int64_t seg0) -> int {
+        const int64_t wbeg = seg0 + (int64_t)wave * SEGW;
+        int cnt = 0;
+        if (wbeg < a1) {
+            double nx, ny, nz, nrw = 0.0;
+            bool nok;
+            auto fetch = [&](int r) {
+                const int64_t a = wbeg + r * 64 + lane;
+                nok = a < a1;
+                const int64_t aa = nok ? a : a1 - 1;
+                nx = pa.coords[3 * aa];
+                ny = pa.coords[3 * aa + 1];
+                nz = pa.coords[3 * aa + 2];
+                if (pa.radii_src == RAD_ATOM) nrw = (double)static_cast<const float *>(pa.radii)[aa];
+                else if (pa.radii_src == RAD_CHANNEL_BY_TYPE) {
+                    const int ty = pa.types[aa];
+                    nok = nok && ty >= 0 && ty < C;
+                    nrw = (double)static_cast<const float *>(pa.radii)[nok ? ty : 0];
+                }
+            };
+            if (pa.radii_src == RAD_SCALAR) nrw = (double)(float)pa.radius_scalar;
+            else if (pa.radii_src == RAD_CHANNEL_FEATURES) nrw = (double)rmax32;
+            fetch(0);
+            for (int r = 0; r < SEG_ROUNDS && wbeg + r * 64 < a1; ++r) {
+                double x = nx, y = ny, z = nz;
+                const double rwin = nrw;
+                bool ok = nok;
+                if (r + 1 < SEG_ROUNDS && wbeg + (r + 1) * 64 < a1) fetch(r + 1);
+                if (has_xf) apply_xform(xf, x, y, z);
+                const double rr = rwin * 1.000001 + 1e-9;
+                ok = ok && (x + rr >= bx0) && (x - rr <= bx1) && (y + rr >= by0) && (y - rr <= by1) && (z + rr >= bz0) &&
+                     (z - rr <= bz1);
+                const unsigned long long mk = __ballot(ok);
+                if (ok)
+                    list[wave * SEGW + cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u))] =
+                        (unsigned short)(wave * SEGW + r * 64 + lane);
+                cnt += __popcll(mk);
+            }
+        }
+        if (lane == 0) wcnt[wave] = cnt;
+        __syncthreads();
+        int total = 0;
+        for (int w = 0; w < NW; ++w) total += wcnt[w];
+        return total;
+    };
+    auto candidate = [&](int j) -> int { // candidate j of the segment (atom order) -> atom index inside the segment
+        int w = 0;
+        while (j >= wcnt[w]) { // j < total: terminates within NW steps
+            j -= wcnt[w];
+            ++w;
+        }
+        return (int)list[w * SEGW + j];
+    };
+
+    // ---- B1. stage candidates [c0, c0 + n) of the segment: records (exact prep) + channel weights -> LDS rows ----
+    auto stage = [&](int64_t seg0, int c0, int n) {
+        // channel weights of the slots this wave stages (slot = wave + u*NW), all loads in flight
+        unsigned v[8];
+        if (pa.mode == MODE_FEATURES) {
+            const float *feat = static_cast<const float *>(pa.features);
+            const bool wl = lane >= 16 && lane < 16 + CT && (L.cbase + lane - 16) < C;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int sl = wave + u * NW;
+                v[u] = 0u;
+                if (sl < n) {
+                    const int64_t a = seg0 + (int64_t)candidate(c0 + sl);
+                    if (wl) v[u] = __float_as_uint(feat[a * C + L.cbase + lane - 16]);
+                }
+            }
+        }
+        // exact prep of this wave's slots: lane u <-> slot wave + u*NW
+        int my_type = 0;
+        {
+            const int sl = wave + lane * NW;
+            if (lane < 8 && sl < n) {
+                const int64_t a = seg0 + (int64_t)candidate(c0 + sl);
+                double p[3] = {pa.coords[3 * a], pa.coords[3 * a + 1], pa.coords[3 * a + 2]};
+                if (has_xf) apply_xform(xf, p[0], p[1], p[2]);
+                AtomRec R;
+                uint32_t rng[3];
+                bool keep = prep_atom(pa, a, p, rmax32, 0.0, R, rng);
+                my_type = R.type;
+                // the binning pass's filters: x range vs the x-slab, y range in SUBY-voxel slabs, z range in
+                // SUBZ-voxel sub-tiles vs this slab's sub-tiles
+                const int xlo = (int)(rng[0] & 0xffff), xhi = (int)(rng[0] >> 16);
+                const int ylo = (int)(rng[1] & 0xffff) >> SUBY_SH, yhi = (int)(rng[1] >> 16) >> SUBY_SH;
+                const int zlo = (int)(rng[2] & 0xffff) >> SUBZ_SH, zhi = (int)(rng[2] >> 16) >> SUBZ_SH;
+                keep = keep && (xlo <= x0 + SUBX - 1) && (xhi >= x0) && (ylo <= sy) && (yhi >= sy) && (zlo <= zt_hi) &&
+                       (zhi >= zt_lo);
+                const uint4 *src = reinterpret_cast<const uint4 *>(&R);
+                uint4 *dst = reinterpret_cast<uint4 *>(un + sl * SW);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[i] = src[i];
+                pk[sl] = keep ? (((unsigned)zlo << 16) | ((unsigned)zhi << 24)) : EMPTY_ENTRY;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sl = wave + u * NW;
+            if (sl < n && lane >= 16 && lane < 16 + (CT < 4 ? 4 : CT)) {
+                unsigned w;
+                if (pa.mode == MODE_FEATURES) w = v[u];
+                else if (pa.mode == MODE_TYPES) w = (__builtin_amdgcn_readlane(my_type, u) == L.cbase + lane - 16) ? 0x3f800000u : 0u;
+                else w = (lane == 16) ? 0x3f800000u : 0u;
+                un[sl * SW + lane] = w;
+            }
+        }
+        __syncthreads();
+    };
+
+    // The first round of the first segment is staged BEFORE the accumulators exist: the candidate prep (fp64 culls,
+    // thresholds, one lane per candidate) then has the whole register file, and per-molecule calls rarely need more
+    // than this one round per slab. Later rounds / segments run the same code with the accumulators live.
+    int total = 0;
+    if (a1 > a0) {
+        total = scan(a0);
+        if (total > 0) stage(a0, 0, total < RW ? total : RW);
+    }
+    const bool any = total > 0;
+    typename Ops::Acc acc;
+    Ops::zero(acc);
+    // ---- B2. walk the n staged rows ---------------------------------------------------------------------------
+    auto walk = [&](int n) {
+        const unsigned pkl = lane < n ? pk[lane] : EMPTY_ENTRY;
+        const bool ok = ((int)((pkl >> 16) & 0xff) <= L.zt_w) && ((int)(pkl >> 24) >= L.zt_w);
+        unsigned long long mask = __ballot(ok);
+        while (mask) {
+            const int sl = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            Ops::accumulate(acc, un + sl * SW, L, P, Tc_s - L.cbase, kc_s - L.cbase);
+        }
+        __syncthreads(); // rows / pk consumed before the next round (or the next segment's list) overwrites them
+    };
+    bool more = false; // candidates beyond the first segment: the zero-fill shortcut of an empty slab no longer applies
+    if (total > 0) {
+        walk(total < RW ? total : RW);
+        for (int c0 = RW; c0 < total; c0 += RW) {
+            const int n = (total - c0) < RW ? (total - c0) : RW;
+            stage(a0, c0, n);
+            walk(n);
+        }
+    }
+    for (int64_t seg0 = a0 + SEGN; seg0 < a1; seg0 += SEGN) {
+        const int tot = scan(seg0);
+        more = more || tot > 0;
+        for (int c0 = 0; c0 < tot; c0 += RW) {
+            const int n = (tot - c0) < RW ? (tot - c0) : RW;
+            stage(seg0, c0, n);
+            walk(n);
+        }
+    }
+    Ops::write(acc, any || more, un, tid, lane, wave, NW, b, L, x0, y0, z0, out, P);
+}
+
+// ------------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------------
 struct KernelKey {
@@ -1189,6 +1469,37 @@ struct Dense64Fn {
         }
     }
 };
+
+struct DirectFn {
+    const DirectArgs &d;
+    const VoxParams &p;
+    float *out;
+    hipStream_t s;
+    template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
+    hipError_t operator()() const {
+        if constexpr (MAXT != 512) {
+            return hipErrorInvalidValue;
+        } else {
+            if (p.B <= 0) return hipSuccess;
+            if ((long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
+            static LdsLimit raised;
+            const size_t lds = direct_lds_bytes(CT, p.NW);
+            auto kern = &voxelize_direct_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>;
+            hipError_t e = raise_lds_limit(kern, lds, raised);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(p.B * p.ncc)), dim3(p.NW * 64), lds, s, d,
+                               out, p);
+            return hipGetLastError();
+        }
+    }
+};
+
+hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, bool chanwise,
+                                  bool lane_range, hipStream_t s) {
+    if (p.NW > 8) return hipErrorInvalidConfiguration;
+    KernelKey k{ct, gauss, chanwise, chanwise ? true : lane_range, 512};
+    return for_kernel(k, DirectFn{d, p, out, s});
+}
 
 hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {
     KernelKey k{ct, gauss, chanwise, chanwise ? true : lane_range, a.p.NW <= 8 ? 512 : 1024};

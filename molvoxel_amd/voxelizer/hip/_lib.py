@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC, "libmvx_hip.so")
 MVX_HOST, MVX_DEVICE = 0, 1
 MVX_GAUSSIAN, MVX_BINARY = 0, 1
 MVX_RADII_SCALAR, MVX_RADII_ATOM, MVX_RADII_CHANNEL = 0, 1, 2
-MVX_XF_CENTER, MVX_XF_ROTATE, MVX_XF_TRANSLATE, MVX_XF_RECENTER = 1, 2, 4, 8
+MVX_XF_CENTER, MVX_XF_ROTATE, MVX_XF_TRANSLATE, MVX_XF_RECENTER, MVX_XF_CENTER_PTR = 1, 2, 4, 8, 16
 
 
 class MvxConfig(C.Structure):
@@ -37,6 +37,7 @@ class MvxXform(C.Structure):
         ("quat", C.c_double * 4),
         ("trans", C.c_float * 3),
         ("flags", C.c_uint32),
+        ("center_ptr", C.c_void_p),
     ]
 
 

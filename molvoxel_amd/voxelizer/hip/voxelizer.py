@@ -32,6 +32,12 @@ def _is_torch(x) -> bool:
     return torch is not None and isinstance(x, torch.Tensor)
 
 
+try:  # the raw stream handle without building a torch.cuda.Stream object per call (~1.5 us -> ~0.2 us)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except Exception:  # pragma: no cover
+    _raw_stream = None
+
+
 def _np_isscalar(x) -> bool:
     return np.isscalar(x)
 
@@ -68,6 +74,8 @@ class Voxelizer(BaseVoxelizer):
         self._handle = _lib.Handle()
         self._types_cache = None
         self._types_i32 = None
+        self._xf = _lib.MvxXform()  # reused per call: the library copies it before the call returns
+        self._xf_addr = C.addressof(self._xf)
         self._has_torch_cuda = torch is not None and torch.cuda.is_available()  # asked on every call otherwise
         cfg = _lib.MvxConfig(
             float(resolution),
@@ -165,9 +173,12 @@ class Voxelizer(BaseVoxelizer):
     # ------------------------------------------------------------------------------------------
     # argument plumbing
     def _stream(self):
+        """The caller's current torch stream as a hipStream_t value (0 = the null stream)."""
         if self._has_torch_cuda:
-            return C.c_void_p(torch.cuda.current_stream(self._device_index).cuda_stream)
-        return C.c_void_p(0)
+            if _raw_stream is not None:
+                return _raw_stream(self._device_index)
+            return torch.cuda.current_stream(self._device_index).cuda_stream
+        return 0
 
     def _on_device(self, x) -> bool:
         return _is_torch(x) and x.is_cuda and x.device.index == self._device_index
@@ -210,30 +221,43 @@ class Voxelizer(BaseVoxelizer):
 
     @staticmethod
     def _ptr(x):
+        """Address for a `void *` argument (ctypes takes None / int)."""
         if x is None:
-            return C.c_void_p(0)
+            return None
         if _is_torch(x):
-            return C.c_void_p(x.data_ptr())
-        return C.c_void_p(x.ctypes.data)
+            return x.data_ptr()
+        return x.ctypes.data
 
-    def _make_xform(self, center, random_translation, random_rotation, coords_dtype_is_f32=False):
-        """One mvx_xform: centring + the random transform drawn in the reference's RNG order."""
-        xf = _lib.MvxXform()
+    def _make_xform(self, center, random_translation, random_rotation, on_device=False, keep=None):
+        """Address of one mvx_xform (the library copies it during the call): centring + the random transform drawn in
+        the reference's RNG order. A `center` tensor on this device is handed over by pointer (MVX_XF_CENTER_PTR) when
+        the coordinates live there too: its value never visits the host, so the call does not synchronise."""
+        xf = self._xf
         flags = 0
         if center is not None:
-            cen = center.detach().cpu().numpy() if _is_torch(center) else np.asarray(center)
-            cen = cen.reshape(3).astype(np.float64)
-            xf.center[:] = cen.tolist()
-            flags |= _lib.MVX_XF_CENTER
-        translation, quaternion = draw_forward_transform(random_translation, random_rotation)
-        if quaternion is not None:
-            xf.quat[:] = [float(q) for q in quaternion]
-            flags |= _lib.MVX_XF_ROTATE
-        if translation is not None:
-            xf.trans[:] = translation.reshape(3).tolist()
-            flags |= _lib.MVX_XF_TRANSLATE
+            if on_device and self._on_device(center):
+                cen = center if (center.dtype == torch.float64 and center.is_contiguous()) else center.to(torch.float64).contiguous()
+                assert cen.numel() == 3, "center should be Array[3,]"
+                if keep is not None:
+                    keep.append(cen)
+                xf.center_ptr = cen.data_ptr()
+                flags |= _lib.MVX_XF_CENTER | _lib.MVX_XF_CENTER_PTR
+            else:
+                cen = center.detach().cpu().numpy() if _is_torch(center) else np.asarray(center)
+                cen = cen.reshape(3).astype(np.float64)
+                xf.center[0], xf.center[1], xf.center[2] = float(cen[0]), float(cen[1]), float(cen[2])
+                flags |= _lib.MVX_XF_CENTER
+        if random_rotation or (random_translation is not None and random_translation > 0.0):
+            translation, quaternion = draw_forward_transform(random_translation, random_rotation)
+            if quaternion is not None:
+                xf.quat[0], xf.quat[1], xf.quat[2], xf.quat[3] = (float(q) for q in quaternion)
+                flags |= _lib.MVX_XF_ROTATE
+            if translation is not None:
+                t = translation.reshape(3)
+                xf.trans[0], xf.trans[1], xf.trans[2] = float(t[0]), float(t[1]), float(t[2])
+                flags |= _lib.MVX_XF_TRANSLATE
         xf.flags = flags
-        return xf
+        return self._xf_addr if flags else None
 
     def _resolve_out(self, out_grid, shape):
         """Returns (buffer passed to the library, out_kind, object to return)."""
@@ -272,13 +296,15 @@ class Voxelizer(BaseVoxelizer):
         self._check_args_features(coords, features, radii, out_grid)
         C_ = features.shape[1]
         c, f, r, in_kind, keep = self._prepare_inputs(coords, features, "features", radii)
-        xf = self._make_xform(center, random_translation, random_rotation)
+        xf = self._make_xform(center, random_translation, random_rotation, in_kind == _lib.MVX_DEVICE, keep)
         buf, out_kind, ret, how = self._resolve_out(out_grid, (C_,))
-        rs = float(radii) if _np_isscalar(radii) else 0.0
-        _lib.check(self._lib.mvx_forward_features(
+        rs = float(radii) if r is None else 0.0
+        rc = self._lib.mvx_forward_features(
             self._handle, self._ptr(c), self._ptr(f), self._ptr(r), rs, self._radii_type_code(), c.shape[0], C_,
-            C.cast(C.byref(xf), C.c_void_p), self._ptr(buf), in_kind, out_kind, self._stream()))
-        return self._finish_out(buf, ret, how)
+            xf, self._ptr(buf), in_kind, out_kind, self._stream())
+        if rc:
+            _lib.check(rc)
+        return self._finish_out(buf, ret, how) if how else ret
 
     def _check_args_features(self, coords, features, radii, out_grid=None):
         V = coords.shape[0]
@@ -314,13 +340,15 @@ class Voxelizer(BaseVoxelizer):
             # channel-wise radii are indexed by type only; pad so the (C,) contract of the ABI holds
             pad = C_ - r.shape[0]
             r = torch.cat([r, r.new_ones(pad)]) if _is_torch(r) else np.concatenate([r, np.ones(pad, self.fp)])
-        xf = self._make_xform(center, random_translation, random_rotation)
+        xf = self._make_xform(center, random_translation, random_rotation, in_kind == _lib.MVX_DEVICE, keep)
         buf, out_kind, ret, how = self._resolve_out(out_grid, (C_,))
-        rs = float(radii) if _np_isscalar(radii) else 0.0
-        _lib.check(self._lib.mvx_forward_types(
+        rs = float(radii) if r is None else 0.0
+        rc = self._lib.mvx_forward_types(
             self._handle, self._ptr(c), self._ptr(t), self._ptr(r), rs, self._radii_type_code(), c.shape[0], int(C_),
-            C.cast(C.byref(xf), C.c_void_p), self._ptr(buf), in_kind, out_kind, self._stream()))
-        return self._finish_out(buf, ret, how)
+            xf, self._ptr(buf), in_kind, out_kind, self._stream())
+        if rc:
+            _lib.check(rc)
+        return self._finish_out(buf, ret, how) if how else ret
 
     def _types_as_int32(self, t):
         """Device types in the ABI's int32, through int16 like the reference's cast (numpy/voxelizer.py:269).
@@ -370,13 +398,15 @@ class Voxelizer(BaseVoxelizer):
         """coords (V,3), center (3,) | None, radii scalar | (V,); out (1,D,H,W)."""
         self._check_args_single(coords, radii, out_grid)
         c, _, r, in_kind, keep = self._prepare_inputs(coords, None, None, radii)
-        xf = self._make_xform(center, random_translation, random_rotation)
+        xf = self._make_xform(center, random_translation, random_rotation, in_kind == _lib.MVX_DEVICE, keep)
         buf, out_kind, ret, how = self._resolve_out(out_grid, (1,))
-        rs = float(radii) if _np_isscalar(radii) else 0.0
-        _lib.check(self._lib.mvx_forward_single(
+        rs = float(radii) if r is None else 0.0
+        rc = self._lib.mvx_forward_single(
             self._handle, self._ptr(c), self._ptr(r), rs, self._radii_type_code(), c.shape[0],
-            C.cast(C.byref(xf), C.c_void_p), self._ptr(buf), in_kind, out_kind, self._stream()))
-        return self._finish_out(buf, ret, how)
+            xf, self._ptr(buf), in_kind, out_kind, self._stream())
+        if rc:
+            _lib.check(rc)
+        return self._finish_out(buf, ret, how) if how else ret
 
     def _check_args_single(self, coords, radii, out_grid=None):
         V = coords.shape[0]
@@ -421,23 +451,31 @@ class Voxelizer(BaseVoxelizer):
             pad = int(C_) - r.shape[0]
             r = torch.cat([r, r.new_ones(pad)]) if _is_torch(r) else np.concatenate([r, np.ones(pad, self.fp)])
         need_xf = centers is not None or random_rotation or (random_translation and random_translation > 0.0)
-        xf_ptr = C.c_void_p(0)
+        xf_ptr = None
         if need_xf:
             xfs = (_lib.MvxXform * B)()
-            cen = None
+            cen = dev_cen = None
             if centers is not None:
-                cen = centers.detach().cpu().numpy() if _is_torch(centers) else np.asarray(centers)
-                cen = cen.reshape(B, 3)
+                if in_kind == _lib.MVX_DEVICE and self._on_device(centers):  # by pointer: no copy to the host
+                    dev_cen = centers.to(torch.float64).contiguous().reshape(B, 3)
+                    keep.append(dev_cen)
+                else:
+                    cen = centers.detach().cpu().numpy() if _is_torch(centers) else np.asarray(centers)
+                    cen = cen.reshape(B, 3)
             for b in range(B):
-                xfs[b] = self._make_xform(None if cen is None else cen[b], random_translation, random_rotation)
-            xf_ptr = C.cast(xfs, C.c_void_p)
+                self._make_xform(None if cen is None else cen[b], random_translation, random_rotation)
+                if dev_cen is not None:
+                    self._xf.center_ptr = dev_cen.data_ptr() + 24 * b
+                    self._xf.flags |= _lib.MVX_XF_CENTER | _lib.MVX_XF_CENTER_PTR
+                C.memmove(C.addressof(xfs) + b * C.sizeof(_lib.MvxXform), self._xf_addr, C.sizeof(_lib.MvxXform))
+            xf_ptr = C.addressof(xfs)
         if out_grid is None:
             out_grid = self.get_empty_grid(C_, batch_size=B)
         assert tuple(out_grid.shape) == (B,) + self.grid_dimension(C_), (
             f"Output grid dimension incorrect: {tuple(out_grid.shape)} vs {(B,) + self.grid_dimension(C_)}")
         buf, out_kind, ret, how = self._resolve_out(out_grid, None)
         rs = float(radii) if _np_isscalar(radii) else 0.0
-        off_ptr = C.c_void_p(offsets.ctypes.data)
+        off_ptr = offsets.ctypes.data
         rt = self._radii_type_code()
         if kind == "features":
             rc = self._lib.mvx_forward_features_batch(self._handle, self._ptr(c), self._ptr(ch), self._ptr(r), rs, rt,
@@ -531,9 +569,8 @@ def transform_on_device(coords, center, translation, quaternion):
     xf.flags = flags
     src = coords.to(torch.float64).contiguous()
     out = torch.empty_like(src)
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    _lib.check(lib.mvx_transform_coords(vox._handle, C.c_void_p(src.data_ptr()), src.shape[0],
-                                        C.cast(C.byref(xf), C.c_void_p), C.c_void_p(out.data_ptr()),
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.mvx_transform_coords(vox._handle, src.data_ptr(), src.shape[0], C.addressof(xf), out.data_ptr(),
                                         _lib.MVX_DEVICE, _lib.MVX_DEVICE, stream))
     return out
 

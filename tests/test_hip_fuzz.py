@@ -95,9 +95,21 @@ def _run(mv, case, precision):
         grid.fill_(7.0)  # stale content must be overwritten
     else:
         grid.fill(7.0)
+    # both routes through the library: the binned three-launch pipeline and the single-launch direct kernel must
+    # produce the same bits (same candidates, same atom order)
+    v.debug_option("direct", 0)
     out = v.forward(coords_in, center_in, chan_in, radii_in, out_grid=grid)
     assert out is grid
-    out = out.cpu().numpy() if isinstance(out, torch.Tensor) else out
+    out = out.cpu().numpy().copy() if isinstance(out, torch.Tensor) else out.copy()
+    if precision == 32:
+        v.debug_option("direct", 1)
+        if case["device"]:
+            grid.fill_(3.0)
+        else:
+            grid.fill(3.0)
+        again = v.forward(coords_in, center_in, chan_in, radii_in, out_grid=grid)
+        again = again.cpu().numpy() if isinstance(again, torch.Tensor) else again
+        assert np.array_equal(out, again), "direct kernel and binned pipeline disagree"
     return out, (coords - center if center is not None else coords)
 
 
@@ -135,6 +147,7 @@ def test_random_configuration_with_random_transform(seed):
     v = mv.create_voxelizer(case["res"], case["D"], case["radii_type"], case["density"], "hip", sigma=case["sigma"],
                             output="numpy", **extra)
     nch = {"features": case["C"], "types": case["C"], "single": 1}[case["mode"]]
+    v.debug_option("direct", seed % 2)  # the transform runs in prep_kernel (binned) or in the scan (direct)
     np.random.seed(seed)
     out = v.forward(case["xyz"], case["center"], case["chan"], case["radii"], 0.7, True, out_grid=v.get_empty_grid(nch))
     # replay: same RNG state -> same draw -> the reference's transform arithmetic on the host (float64)
@@ -180,8 +193,12 @@ def test_random_batches(seed):
     radii = {"scalar": 1.3 * res / 0.5, "atom-wise": np.concatenate(r_atom), "channel-wise": r_chan}[radii_type]
     offsets = np.cumsum([0] + sizes)
     v = mv.create_voxelizer(res, D, radii_type, density, "hip", sigma=0.6, output="numpy")
-    out = v.forward_batch(np.concatenate(coords), offsets, centers, chan, radii, num_channels=C_)
+    v.debug_option("direct", 0)
+    out = v.forward_batch(np.concatenate(coords), offsets, centers, chan, radii, num_channels=C_).copy()
     assert out.shape == (B, C_, D, D, D)
+    v.debug_option("direct", 1)
+    assert np.array_equal(out, v.forward_batch(np.concatenate(coords), offsets, centers, chan, radii, num_channels=C_)), \
+        "direct kernel and binned pipeline disagree"
     for b, n in enumerate(sizes):
         if n == 0:
             assert not out[b].any()

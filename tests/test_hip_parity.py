@@ -50,11 +50,15 @@ def _compare(out, ref, exact):
         assert_gaussian(out, ref)  # tests/tolerance.py: membership identical, |d| <= 5e-6 * max(1, |ref|) per voxel
 
 
+@pytest.mark.parametrize("route", ["binned", "direct"])
 @pytest.mark.parametrize("case", IDX_SMALL, ids=[c["id"] for c in IDX_SMALL])
-def test_small_golden(mv, case):
+def test_small_golden(mv, case, route):
+    """Every small golden through both routes of the library: the binned three-launch pipeline and the
+    single-launch direct kernel (what per-molecule calls take by default)."""
     coords, chan, radii = goldens.small_case_inputs(Z_SMALL, case)
     ref = Z_SMALL[f"{case['id']}/out"]
     v = _make(mv, case)
+    v.debug_option("direct", 1 if route == "direct" else 0)
     out = v.forward(coords, None, chan, radii)
     _compare(out, ref, exact=(case["density"] == "binary" and case["mode"] != "features"))
     if case["density"] == "binary" and case["mode"] == "features":
@@ -180,7 +184,7 @@ def test_c_abi_direct_host_pointers(mv):
     from oracle import c_oracle
 
     lib = _lib.load()
-    assert lib.mvx_version() == 110
+    assert lib.mvx_version() == 120
     wl = W.cfg3()
     cfg = _lib.MvxConfig(0.5, 0.5, 48, 8, _lib.MVX_BINARY, 0, 32, 0)
     h = _lib.Handle()
@@ -302,12 +306,17 @@ def test_dense_cluster_exceeds_candidate_capacity(mv):
     xyz = rng.normal(scale=0.8, size=(3000, 3))
     t = rng.integers(0, 3, 3000)
     v = mv.create_voxelizer(0.5, 24, "scalar", "binary", "hip", output="numpy")
-    out = v.forward(xyz, None, t, 1.0)
     ref = c_oracle.voxelize(xyz, t, 1.0, dimension=24, density="binary", num_channels=3)
-    assert np.array_equal(out, ref)
+    for route in (0, 1):  # binned: overflow list + dense kernel; direct: many rounds per slab
+        v.debug_option("direct", route)
+        assert np.array_equal(v.forward(xyz, None, t, 1.0), ref)
     f = rng.random((3000, 32)).astype(np.float32)
     vg = mv.create_voxelizer(0.5, 24, "scalar", "gaussian", "hip", output="numpy")
+    vg.debug_option("direct", 1)
+    outd = vg.forward(xyz, None, f, 1.0).copy()
+    vg.debug_option("direct", 0)
     outg = vg.forward(xyz, None, f, 1.0)
+    assert np.array_equal(outd, outg)
     refg = c_oracle.voxelize(xyz, f, 1.0, dimension=24)
     assert_gaussian(outg, refg)  # sums of ~1000 terms: the relative branch of the rule
 
@@ -322,10 +331,12 @@ def test_medium_density_multi_round_slab_lines(mv):
     xyz = rng.uniform(-W_ / 2, W_ / 2, (2000, 3))
     t = rng.integers(0, 5, 2000)
     v = mv.create_voxelizer(0.5, D, "scalar", "binary", "hip", output="numpy")
+    v.debug_option("direct", 0)
     out = v.forward(xyz, None, t, 1.5)
     assert np.array_equal(out, c_oracle.voxelize(xyz, t, 1.5, dimension=D, density="binary", num_channels=5))
     f = rng.random((2000, 32)).astype(np.float32)
     vg = mv.create_voxelizer(0.5, D, "scalar", "gaussian", "hip", output="numpy")
+    vg.debug_option("direct", 0)
     outg = vg.forward(xyz, None, f, 1.5)
     refg = c_oracle.voxelize(xyz, f, 1.5, dimension=D)
     assert_gaussian(outg, refg)  # sums of up to ~60 terms
@@ -342,8 +353,10 @@ def test_long_x_list_beyond_lds_copy(mv):
     xyz[:, 0] = rng.uniform(-0.4, 0.4, 9000)  # a plate: every atom in the same two or three x-slabs
     t = rng.integers(0, 4, 9000)
     v = mv.create_voxelizer(0.5, D, "scalar", "binary", "hip", output="numpy")
-    out = v.forward(xyz, None, t, 1.0)
-    assert np.array_equal(out, c_oracle.voxelize(xyz, t, 1.0, dimension=D, density="binary", num_channels=4))
+    ref = c_oracle.voxelize(xyz, t, 1.0, dimension=D, density="binary", num_channels=4)
+    for route in (0, 1):  # direct: three scan segments of 4096 atoms, hundreds of candidates per slab
+        v.debug_option("direct", route)
+        assert np.array_equal(v.forward(xyz, None, t, 1.0), ref)
 
 
 def test_ragged_batch_with_one_large_molecule(mv):
