@@ -88,6 +88,7 @@ struct mvx_handle {
     // -1: the library picks (run()); 0: always the binned three-launch pipeline; 1: always voxelize_direct_kernel
     // (where it applies: float32 grids). Set by mvx_debug_set_option("direct", v) in tests and A/B runs.
     int direct_mode = -1;
+    int dbg = 0; // diagnostic builds (-DMVX_DIAG) only
     int store_kind = 1; // nt: measured 0.69 -> 0.54 ms on cfg-2 (output lines do not displace the re-read inputs in L2)
 };
 
@@ -486,6 +487,9 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.store_kind = h->store_kind;
     va.p.pace = (nslabs * (size_t)ncc > 4096) ? 1 : 0;
     va.p.sigma = h->cfg.sigma;
+#ifdef MVX_DIAG
+    va.p.dbg = h->dbg;
+#endif
     // a sub-tile lies inside one reference block when its edges divide blockdim (or there is a single block):
     // the block cull is then wave-uniform and already folded into the candidate ranges.
     const bool lane_range = !(g.nb == 1 || (g.bd % SUBX == 0 && g.bd % SUBY == 0 && g.bd % SUBZ == 0));
@@ -494,10 +498,17 @@ int run(mvx_handle *h, const RunArgs &r) {
         DirectArgs da;
         da.pa = pa;
         da.pa.rec = nullptr;
+#ifdef MVX_DIAG // stamps of every workgroup (8 x 8 B each), read back with mvx_debug_read_records
+        if ((rc = ensure(h->rec, nslabs * (size_t)ncc * 64))) return rc;
+        da.pa.rec = reinterpret_cast<AtomRec *>(h->rec.p);
+#endif
         da.pa.wbuf = nullptr;
         da.pa.xp = nullptr;
         da.pa.chan_aux = nullptr;
         da.N = total;
+        da.T_scalar = -1.0;
+        da.k_scalar = 0.0f;
+        if (r.radii_type == MVX_RADII_SCALAR) scalar_radius_constants(r.radius_scalar, h->sigma32, gauss, &da.T_scalar, &da.k_scalar);
         std::memset(&da.xf, 0, sizeof(da.xf));
         if (r.B == 1) { // one molecule: extent and transform by value, no metadata on the device
             da.pa.offsets = nullptr;
@@ -814,6 +825,9 @@ int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
     if (n == "chunks") h->pipeline = std::max(1, std::min(16, (int)value));
     else if (n == "max_ct") h->max_ct = std::max(1, std::min(32, (int)value));
     else if (n == "direct") h->direct_mode = value < 0 ? -1 : (value ? 1 : 0);
+#ifdef MVX_DIAG
+    else if (n == "dbg") h->dbg = value;
+#endif
     else return fail(MVX_ERR_INVALID, "unknown option: " + n);
     return MVX_OK;
 }

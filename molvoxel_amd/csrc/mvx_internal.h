@@ -83,6 +83,9 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
     int32_t store_kind;    // 0 plain, 1 nt, 2 sc1 (MVX_STORE)
     int32_t pace;          // 1: empty slabs hold their stores back ~1.7 us (launches of more than 4096 workgroups)
     double sigma;          // float64 grids: the Gaussian sigma as the reference holds it (python float)
+#ifdef MVX_DIAG
+    int32_t dbg;           // diagnostic builds: run-time ablation switches of voxelize_direct_kernel
+#endif
 };
 
 // voxelize_direct_kernel: the atoms as the caller passed them (PrepArgs without workspace pointers) plus, for a
@@ -91,6 +94,8 @@ struct DirectArgs {
     PrepArgs pa;   // rec / wbuf / xp / chan_aux unused; offsets / xforms: device arrays, or null for one molecule
     mvx_xform xf;  // the transform when pa.xforms is null (flags == 0: none)
     int64_t N;     // atoms of the only molecule when pa.offsets is null
+    double T_scalar; // RAD_SCALAR: d2_threshold(float(radius)) and gauss_coeff, evaluated once on the host
+    float k_scalar;
 };
 
 struct VoxArgs {
@@ -127,6 +132,7 @@ hipError_t launch_voxelize_dense(const VoxArgs &a, int32_t ct, bool gauss, bool 
 // the whole call in one launch (float32 grids, NW <= 8): no workspace, no pre-pass
 hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, bool chanwise,
                                   bool lane_range, hipStream_t s);
+void scalar_radius_constants(double radius_scalar, float sigma32, bool gauss, double *T, float *k);
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW);
 int32_t voxelize_dcap(int32_t ct, int32_t NW);
 

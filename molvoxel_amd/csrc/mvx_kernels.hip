@@ -30,6 +30,7 @@
 #include "mvx_internal.h"
 
 #include <math.h>
+#include <type_traits>
 #include <stdio.h>
 #include <cstdlib>
 
@@ -43,19 +44,32 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double next_up(double x) { // x > 0 finite
-    return __longlong_as_double(__double_as_longlong(x) + 1);
+__host__ __device__ __forceinline__ double next_up(double x) { // x > 0 finite
+    long long b;
+    __builtin_memcpy(&b, &x, 8);
+    b += 1;
+    __builtin_memcpy(&x, &b, 8);
+    return x;
 }
-__device__ __forceinline__ double next_down(double x) { // x > 0 finite
-    return __longlong_as_double(__double_as_longlong(x) - 1);
+__host__ __device__ __forceinline__ double next_down(double x) { // x > 0 finite
+    long long b;
+    __builtin_memcpy(&b, &x, 8);
+    b -= 1;
+    __builtin_memcpy(&x, &b, 8);
+    return x;
 }
 
 // Largest fp64 d2 with float32(float32(sqrt(d2)) / r32) <= 1 (sqrt and division correctly rounded).
-__device__ double d2_threshold(float r32) {
+// (IEEE operations only - conversions, one product, one fma - so the host evaluates it to the same bits.)
+__host__ __device__ double d2_threshold(float r32) {
     if (!(r32 > 0.0f) || !(r32 < 3.0e38f)) return -1.0;
-    const float up = __uint_as_float(__float_as_uint(r32) + 1u);
+    unsigned rb;
+    __builtin_memcpy(&rb, &r32, 4);
+    const unsigned ub_ = rb + 1u;
+    float up;
+    __builtin_memcpy(&up, &ub_, 4);
     const double m = 0.5 * ((double)r32 + (double)up); // midpoint between r32 and the next float (exact)
-    const bool even = (__float_as_uint(r32) & 1u) == 0u;
+    const bool even = (rb & 1u) == 0u;
     const double y = even ? m : next_down(m); // largest fp64 that rounds (ties-to-even) to <= r32
     const double yp = next_up(y);
     const double hi = y * yp;
@@ -63,7 +77,7 @@ __device__ double d2_threshold(float r32) {
     return (lo >= 0.0) ? hi : next_down(hi);
 }
 
-__device__ __forceinline__ float gauss_coeff(float r32, float sigma32) {
+__host__ __device__ __forceinline__ float gauss_coeff(float r32, float sigma32) {
     const double rs = (double)r32 * (double)sigma32;
     return (float)(-0.5 * 1.4426950408889634 / (rs * rs));
 }
@@ -111,6 +125,67 @@ __device__ void apply_xform(const mvx_xform &xf, double &x, double &y, double &z
         y = y + t1;
         z = z + t2;
     }
+}
+
+// The same transform in float32, for the direct kernel's candidate scan only: a cheap estimate of where the atom lands,
+// p' = M (p - c) + o with M the matrix of q p conj(q) (identity without a rotation). Every float32 operation is off by
+// at most 2^-24 of its result and all intermediates are bounded by s (|p|_1 + |c|_1) + |o|_1, s = max(1, |q|^2), on
+// paths a handful of operations deep: the estimate is within ~1e-6 of that magnitude of the float64 result. The scan
+// widens every test by SCAN_MARGIN (2e-5) times the magnitude, so its candidate set stays a superset; membership is
+// decided later in float64 (prep_atom / the stage step), never here.
+constexpr float SCAN_MARGIN = 2.0e-5f;
+// Workgroup-uniform values that the vector ALU computed (there is no scalar float arithmetic) are moved to scalar
+// registers explicitly: left in VGPRs they are the first thing the allocator spills, and one scratch reload inside
+// a dependent chain costs a memory round trip.
+__device__ __forceinline__ float uniform(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ double uniform(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+struct XformF32 {
+    float c0, c1, c2;                                  // subtracted first
+    float m00, m01, m02, m10, m11, m12, m20, m21, m22; // rotation (only when rot)
+    float o0, o1, o2;                                  // added last
+    float scale;                                       // max(1, |q|^2)
+    float mag;                                         // scale * |c|_1 + |o|_1 + 1
+    bool rot;
+};
+__device__ __forceinline__ XformF32 make_xform_f32(const mvx_xform &xf) {
+    XformF32 X;
+    double c0 = xf.center[0], c1 = xf.center[1], c2 = xf.center[2];
+    if (xf.flags & MVX_XF_CENTER_PTR) {
+        c0 = xf.center_ptr[0];
+        c1 = xf.center_ptr[1];
+        c2 = xf.center_ptr[2];
+    }
+    const bool cen = (xf.flags & MVX_XF_CENTER) != 0, rot = (xf.flags & MVX_XF_ROTATE) != 0;
+    const bool tr = (xf.flags & MVX_XF_TRANSLATE) != 0, rec = rot && (xf.flags & MVX_XF_RECENTER) != 0;
+    X.rot = rot;
+    X.c0 = cen ? (float)c0 : 0.0f;
+    X.c1 = cen ? (float)c1 : 0.0f;
+    X.c2 = cen ? (float)c2 : 0.0f;
+    const float tm = tr ? (rot ? 2.0f : 1.0f) : 0.0f; // the translation is applied twice after a rotation (quirk Q4)
+    X.o0 = tm * xf.trans[0] + (rec ? (float)c0 : 0.0f);
+    X.o1 = tm * xf.trans[1] + (rec ? (float)c1 : 0.0f);
+    X.o2 = tm * xf.trans[2] + (rec ? (float)c2 : 0.0f);
+    const float q0 = (float)xf.quat[0], q1 = (float)xf.quat[1], q2 = (float)xf.quat[2], q3 = (float)xf.quat[3];
+    X.m00 = q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3;
+    X.m01 = 2.0f * (q1 * q2 - q0 * q3);
+    X.m02 = 2.0f * (q1 * q3 + q0 * q2);
+    X.m10 = 2.0f * (q1 * q2 + q0 * q3);
+    X.m11 = q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3;
+    X.m12 = 2.0f * (q2 * q3 - q0 * q1);
+    X.m20 = 2.0f * (q1 * q3 - q0 * q2);
+    X.m21 = 2.0f * (q2 * q3 + q0 * q1);
+    X.m22 = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3;
+    const float n2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
+    X.scale = rot ? (n2 > 1.0f ? n2 : 1.0f) * 1.001f : 1.0f;
+    X.mag = X.scale * (fabsf(X.c0) + fabsf(X.c1) + fabsf(X.c2)) + fabsf(X.o0) + fabsf(X.o1) + fabsf(X.o2) + 1.0f;
+    float *fields[] = {&X.c0, &X.c1, &X.c2, &X.m00, &X.m01, &X.m02, &X.m10, &X.m11, &X.m12, &X.m20, &X.m21, &X.m22,
+                       &X.o0, &X.o1, &X.o2, &X.scale, &X.mag};
+    for (float *fp : fields) *fp = uniform(*fp);
+    return X;
 }
 
 __device__ __forceinline__ int find_molecule(const int64_t *offsets, int B, int64_t a) {
@@ -1105,26 +1180,59 @@ __global__ void __launch_bounds__(1024)
 // three-launch pipeline above (prep -> xbin -> voxelize, + an H2D copy of the transform) is all latency: 25-40 us of
 // launches and boundaries around 5-12 us of voxelize work. This kernel needs no workspace and no pre-pass:
 //   grid = (slab, molecule * ncc + channel chunk) as voxelize_kernel. Per workgroup:
-//   A. scan: wave w reads atoms [w*512, (w+1)*512) of the current 512*NW-atom segment straight from the caller's
-//      coords (transform applied in flight), tests the atom's conservative radius window against the slab's box
-//      (a superset of what prep_atom admits) and appends the survivors, by ballot + prefix, to its own region of an
-//      LDS list; one barrier. Regions in wave order = candidates IN ATOM ORDER (so sums are bit-identical to the
-//      binned path's);
-//   B. rounds of up to 64 candidates: lane u < 8 of wave w runs prep_atom (the same exact culls / threshold code the
-//      prep kernel runs) for slot w + u*NW and writes the 64-B record straight into the LDS row, while the wave's
-//      other lanes fetch the slot's channel weights from the caller's feature rows (or build the one-hot / unit row
-//      of forward_types / forward_single); the slab-level x / y / z-sub-tile range filters of the binning pass are
-//      applied here; one barrier; then the unchanged walk (Ops::accumulate) and write-out (Ops::write).
+//   A. scan: wave w takes atoms [w*512, (w+1)*512) of the current 512*NW-atom segment, 128 at a time: the 3 KB of
+//      coordinates are fetched with contiguous 16-B-per-lane loads (the (N,3) rows are 24 B apart: one load per
+//      coordinate would touch every cache line three times, and every workgroup of the chip reads the same lines),
+//      rounded to float32 and transposed through the wave's own LDS strip; the transform is applied in float32 and
+//      the atom's radius window, widened by the float32 error bound (SCAN_MARGIN), is tested against the slab's box:
+//      a superset of the atoms that can reach the slab (the exact float64 decisions are step B's). Survivors are appended, by ballot + prefix, to the wave's region of an LDS
+//      list; one barrier. Regions in wave order = candidates IN ATOM ORDER (sums bit-identical to the binned path's).
+//   B. rounds of up to 64 candidates: lane u < 8 of wave w prepares slot w + u*NW - position, exact box cull and the
+//      cull of the reference blocks this slab lies in (x, y), threshold T, coefficient k - and writes the 64-B record
+//      straight into the LDS row, while the wave's other lanes fetch the slot's channel weights from the caller's
+//      feature rows (or build the one-hot / unit row of forward_types / forward_single); one barrier; every wave
+//      then selects, one lane per row, the rows that pass ITS sub-tile's z block cull and z window, and walks them
+//      (Ops::accumulate); write-out as everywhere (Ops::write).
+//      Sub-tiles that straddle reference blocks (LANE_RANGE: blockdim 4, 5, 12, ...) need per-lane voxel ranges:
+//      those variants run prep_atom per candidate instead, as the prep kernel does.
 //   Any number of candidates and atoms works (rounds, segments); there is no overflow list and no dense kernel.
-// LDS map: u16 list[NW*512] | int wcnt[16] | u32 pk[64] | double Tc[32] | float kc[32] | union { rows ; tile }.
+// LDS map: u16 list[NW*512] | int wcnt[16] | u32 pk[64] | double Tc[32] | float kc[32] | union { scan strips ; rows ; tile }.
 constexpr int SEGW = 512;            // atoms one wave scans per segment
-constexpr int SEG_ROUNDS = SEGW / 64;
+constexpr int SCAN_BLOCK = 128;      // atoms per coalesced fetch (3 x 1 KB)
 constexpr int DIRECT_HDR_BYTES = 64 + 256 + 32 * 8 + 32 * 4; // wcnt + pk + Tc + kc
 
-size_t direct_lds_bytes(int32_t ct, int32_t NW) { return (size_t)NW * SEGW * 2 + DIRECT_HDR_BYTES + voxelize_lds_bytes(ct, NW); }
+size_t direct_lds_bytes(int32_t ct, int32_t NW) {
+    const size_t strips = (size_t)NW * SCAN_BLOCK * 12;
+    const size_t un = voxelize_lds_bytes(ct, NW);
+    return (size_t)NW * SEGW * 2 + DIRECT_HDR_BYTES + (un > strips ? un : strips);
+}
 
+// reference block cull along one axis for the block holding voxel index v (numpy/voxelizer.py:500-513):
+// lo / hi are bounds[b-1] and bounds[b] (numpy/voxelizer.py:55), has_lo / has_hi say whether the comparison applies
+struct BlockBounds {
+    double lo, hi;
+    bool has_lo, has_hi;
+};
+__device__ __forceinline__ BlockBounds block_bounds(const Geom &g, int v) {
+    BlockBounds B;
+    int blk = v / g.bd;
+    if (blk > g.nb - 1) blk = g.nb - 1;
+    const double hres = g.res / 2.0;
+    B.has_lo = g.nb > 1 && blk >= 1;
+    B.has_hi = g.nb > 1 && blk <= g.nb - 2;
+    B.lo = uniform(((double)(blk * g.bd) * g.res - g.half) + hres);       // bounds[blk - 1]
+    B.hi = uniform(((double)((blk + 1) * g.bd) * g.res - g.half) + hres); // bounds[blk]
+    return B;
+}
+__device__ __forceinline__ bool block_admits(const BlockBounds &B, double p, double r) {
+    return (!B.has_lo || p > B.lo - r) && (!B.has_hi || p < B.hi + r);
+}
+
+#ifndef MVX_DIRECT_WPS
+#define MVX_DIRECT_WPS 4
+#endif
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
-__global__ void __launch_bounds__(MAXT, 4)
+__global__ void __launch_bounds__(MAXT, MVX_DIRECT_WPS)
     voxelize_direct_kernel(const DirectArgs A, float *__restrict__ out, const VoxParams P) {
     typedef OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE> Ops;
     constexpr int SW = Ops::SW;
@@ -1139,6 +1247,7 @@ __global__ void __launch_bounds__(MAXT, 4)
     double *Tc_s = reinterpret_cast<double *>(pk + 64);
     float *kc_s = reinterpret_cast<float *>(Tc_s + 32);
     unsigned *un = reinterpret_cast<unsigned *>(kc_s + 32);
+    float *strip = reinterpret_cast<float *>(un) + (size_t)wave * SCAN_BLOCK * 3; // this wave's scan strip
 
     const unsigned t = blockIdx.x;
     int b = (int)blockIdx.y, cc = 0;
@@ -1150,9 +1259,10 @@ __global__ void __launch_bounds__(MAXT, 4)
     decode_slab(t, P, sx, sy, zc);
     const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
     const int zt_lo = zc * NW, zt_hi = zt_lo + NW - 1;
-    const LaneCtx L = make_lane_ctx(lane, wave, x0, y0, z0, zt_lo, cc * CT, P);
+    const int cbase = cc * CT; // first channel of this workgroup's chunk
     const PrepArgs &pa = A.pa;
     const int C = pa.C;
+    const Geom &g = pa.g;
 
     int64_t a0 = 0, a1 = A.N;
     if (pa.offsets) {
@@ -1168,7 +1278,7 @@ __global__ void __launch_bounds__(MAXT, 4)
     if constexpr (CHANWISE) {
         const float *cr = static_cast<const float *>(pa.radii);
         if (tid < CT) {
-            const int ch = (L.cbase + tid < C) ? L.cbase + tid : C - 1;
+            const int ch = (cbase + tid < C) ? cbase + tid : C - 1;
             const float r = cr[ch];
             Tc_s[tid] = d2_threshold(r);
             kc_s[tid] = GAUSS ? gauss_coeff(r, pa.sigma32) : 0.0f;
@@ -1183,106 +1293,189 @@ __global__ void __launch_bounds__(MAXT, 4)
         rmax32 = m;
     }
 
-    // the slab's box, widened per atom by its radius window (superset of prep_atom's admitted ranges)
+    // the slab's box, widened per atom by its radius window (superset of the voxels the atom can reach)
     const int xh = (x0 + SUBX - 1 < P.D - 1) ? x0 + SUBX - 1 : P.D - 1;
     const int yh = (y0 + SUBY - 1 < P.D - 1) ? y0 + SUBY - 1 : P.D - 1;
     const int zh = (z0 + SUBZ * NW - 1 < P.D - 1) ? z0 + SUBZ * NW - 1 : P.D - 1;
     const double slack = 1e-6 * P.res;
-    const double bx0 = (double)x0 * P.res - P.half - slack, bx1 = (double)xh * P.res - P.half + slack;
-    const double by0 = (double)y0 * P.res - P.half - slack, by1 = (double)yh * P.res - P.half + slack;
-    const double bz0 = (double)z0 * P.res - P.half - slack, bz1 = (double)zh * P.res - P.half + slack;
+    const double bx0 = uniform((double)x0 * P.res - P.half - slack), bx1 = uniform((double)xh * P.res - P.half + slack);
+    const double by0 = uniform((double)y0 * P.res - P.half - slack), by1 = uniform((double)yh * P.res - P.half + slack);
+    const double bz0 = uniform((double)z0 * P.res - P.half - slack), bz1 = uniform((double)zh * P.res - P.half + slack);
+    const XformF32 X32 = make_xform_f32(xf);
+    // the box as centre (minus the transform's final offset) and half extents, rounded outwards
+    const float ccx = uniform((float)(0.5 * (bx0 + bx1)) - X32.o0), ccy = uniform((float)(0.5 * (by0 + by1)) - X32.o1),
+                ccz = uniform((float)(0.5 * (bz0 + bz1)) - X32.o2);
+    const float hx = uniform((float)(0.5 * (bx1 - bx0)) * 1.000001f + 1e-6f), hy = uniform((float)(0.5 * (by1 - by0)) * 1.000001f + 1e-6f),
+                hz = uniform((float)(0.5 * (bz1 - bz0)) * 1.000001f + 1e-6f);
 
+    const BlockBounds Bx = block_bounds(g, x0), By = block_bounds(g, y0); // the reference blocks this slab lies in
     const int RW = 8 * NW < 64 ? 8 * NW : 64; // candidate rows per round
     const int64_t SEGN = (int64_t)NW * SEGW;
+    // a molecule that fits one round of rows (ligands) skips the scan: every atom is staged, and the stage's own
+    // x / y window test drops the ones that cannot reach this slab
+    const bool small = (a1 - a0) <= RW;
+    if (tid < 16) wcnt[tid] = 0; // (wave 0, before its own count is stored; the scan's barrier publishes both)
+#ifdef MVX_DIAG // per-workgroup s_memtime stamps into the (otherwise unused) record buffer: diagnostic builds only
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(pa.rec) + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+#define MVX_STAMP(i) do { if (tid == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    if (tid == 0) for (int i = 0; i < 8; ++i) stamps[i] = 0;
+#else
+#define MVX_STAMP(i) do { } while (0)
+#endif
+    MVX_STAMP(0);
+#ifdef MVX_DIAG // run-time ablations (no dead-code elimination, same register allocation): 2 = no atoms at all
+    if (P.dbg & 2) a1 = a0;
+#endif
 
-    // ---- A. scan of one segment: survivors of wave w -> list[w*SEGW ...], counts -> wcnt; returns their number ----
-    // (rolled, the next round's loads issued before this round's arithmetic; regions in wave order = atom order, so
-    // candidate j of the segment is entry j - base[w] of the wave w whose prefix interval holds j: no second pass)
-    auto scan = [&](int64_t seg0) -> int {
-        const int64_t wbeg = seg0 + (int64_t)wave * SEGW;
-        int cnt = 0;
-        if (wbeg < a1) {
-            double nx, ny, nz, nrw = 0.0;
-            bool nok;
-            auto fetch = [&](int r) {
-                const int64_t a = wbeg + r * 64 + lane;
-                nok = a < a1;
-                const int64_t aa = nok ? a : a1 - 1;
-                nx = pa.coords[3 * aa];
-                ny = pa.coords[3 * aa + 1];
-                nz = pa.coords[3 * aa + 2];
-                if (pa.radii_src == RAD_ATOM) nrw = (double)static_cast<const float *>(pa.radii)[aa];
-                else if (pa.radii_src == RAD_CHANNEL_BY_TYPE) {
-                    const int ty = pa.types[aa];
-                    nok = nok && ty >= 0 && ty < C;
-                    nrw = (double)static_cast<const float *>(pa.radii)[nok ? ty : 0];
-                }
-            };
-            if (pa.radii_src == RAD_SCALAR) nrw = (double)(float)pa.radius_scalar;
-            else if (pa.radii_src == RAD_CHANNEL_FEATURES) nrw = (double)rmax32;
-            fetch(0);
-            for (int r = 0; r < SEG_ROUNDS && wbeg + r * 64 < a1; ++r) {
-                double x = nx, y = ny, z = nz;
-                const double rwin = nrw;
-                bool ok = nok;
-                if (r + 1 < SEG_ROUNDS && wbeg + (r + 1) * 64 < a1) fetch(r + 1);
-                if (has_xf) apply_xform(xf, x, y, z);
-                const double rr = rwin * 1.000001 + 1e-9;
-                ok = ok && (x + rr >= bx0) && (x - rr <= bx1) && (y + rr >= by0) && (y - rr <= by1) && (z + rr >= bz0) &&
-                     (z - rr <= bz1);
-                const unsigned long long mk = __ballot(ok);
-                if (ok)
-                    list[wave * SEGW + cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u))] =
-                        (unsigned short)(wave * SEGW + r * 64 + lane);
-                cnt += __popcll(mk);
+    // ---- A. scan of one segment: survivors of wave w -> list[w*SEGW ...], counts -> wcnt; returns their number and
+    //         the exclusive prefixes of the NW counts (scalar registers) ---------------------------------------------
+    auto scan = [&](int64_t seg0, int (&pre)[9]) -> int {
+    const int64_t wbeg = seg0 + (int64_t)wave * SEGW;
+    int cnt = 0;
+    if (!small && wbeg < a1) {
+        const int64_t dend = 3 * a1; // doubles of this molecule end here
+        // the next 128-atom block's six loads are in flight while this block is tested (the loaded doubles stay
+        // untouched in registers until the next iteration: converting them in the fetch would wait for them on the
+        // spot); lane l holds doubles 128k + 2l, 128k + 2l + 1 (k = 0..2) of the 384-double block
+        constexpr int NBLK = SEGW / SCAN_BLOCK;
+        double fd[6];
+        auto fetch = [&](int blk) {
+            const int64_t d0 = 3 * (wbeg + (int64_t)blk * SCAN_BLOCK) + 2 * lane;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { // (clamped addresses, unconditional loads; values past the molecule are never used)
+                const int64_t d = d0 + 128 * k;
+                fd[2 * k] = pa.coords[d < dend ? d : dend - 1];
+                fd[2 * k + 1] = pa.coords[d + 1 < dend ? d + 1 : dend - 1];
             }
-        }
+        };
+        // one copy of the loop per kind of radius (one value for every atom / a load per atom)
+        auto region = [&](auto per_atom_radius) {
+            constexpr bool PER_ATOM = decltype(per_atom_radius)::value;
+            float rscalar = 0.0f;
+            if (pa.radii_src == RAD_SCALAR) rscalar = (float)pa.radius_scalar;
+            else if (pa.radii_src == RAD_CHANNEL_FEATURES) rscalar = rmax32;
+            fetch(0);
+#pragma nounroll
+            for (int blk = 0; blk < NBLK; ++blk) {
+                if (wbeg + blk * SCAN_BLOCK >= a1) break;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    *reinterpret_cast<float2v *>(strip + 128 * k + 2 * lane) = (float2v){(float)fd[2 * k], (float)fd[2 * k + 1]};
+                if (blk + 1 < NBLK && wbeg + (blk + 1) * SCAN_BLOCK < a1) fetch(blk + 1);
+#pragma unroll
+                for (int q = 0; q < SCAN_BLOCK / 64; ++q) {
+                    const int j = 64 * q + lane;
+                    const int64_t a = wbeg + blk * SCAN_BLOCK + j;
+                    bool ok = a < a1;
+                    float x = strip[3 * j], y = strip[3 * j + 1], z = strip[3 * j + 2];
+                    float rwin = rscalar;
+                    if constexpr (PER_ATOM) {
+                        if (pa.radii_src == RAD_ATOM) rwin = static_cast<const float *>(pa.radii)[ok ? a : a1 - 1];
+                        else {
+                            const int ty = pa.types[ok ? a : a1 - 1];
+                            ok = ok & (ty >= 0) & (ty < C);
+                            rwin = static_cast<const float *>(pa.radii)[ok ? ty : 0];
+                        }
+                    }
+                    // float32 estimate of the position; every test widened by the estimate's error bound
+                    const float mag = X32.scale * (fabsf(x) + fabsf(y) + fabsf(z)) + X32.mag;
+                    x -= X32.c0;
+                    y -= X32.c1;
+                    z -= X32.c2;
+                    if (X32.rot) {
+                        const float u = X32.m00 * x + X32.m01 * y + X32.m02 * z;
+                        const float v = X32.m10 * x + X32.m11 * y + X32.m12 * z;
+                        const float w = X32.m20 * x + X32.m21 * y + X32.m22 * z;
+                        x = u;
+                        y = v;
+                        z = w;
+                    }
+                    const float rr = rwin * 1.00001f + SCAN_MARGIN * mag + 1e-6f;
+                    const bool near = (fabsf(x - ccx) <= hx + rr) & (fabsf(y - ccy) <= hy + rr) & (fabsf(z - ccz) <= hz + rr);
+                    ok = ok & (near | !(mag < 1.0e30f)); // magnitudes float32 cannot hold: leave it to the float64 step
+                    const unsigned long long mk = __ballot(ok);
+                    if (ok)
+                        list[wave * SEGW + cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u))] =
+                            (unsigned short)(wave * SEGW + blk * SCAN_BLOCK + j);
+                    cnt += __popcll(mk);
+                }
+            }
+        };
+        if (pa.radii_src == RAD_SCALAR || pa.radii_src == RAD_CHANNEL_FEATURES) region(std::false_type{});
+        else region(std::true_type{});
+    }
+    pre[0] = 0;
+    int total;
+    if (small) { // every atom is a candidate: no scan, no list, no barrier
+        total = (int)(a1 - a0);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) pre[w + 1] = total;
+    } else {
         if (lane == 0) wcnt[wave] = cnt;
         __syncthreads();
-        int total = 0;
-        for (int w = 0; w < NW; ++w) total += wcnt[w];
+        // the NW counts as exclusive prefixes in scalar registers (eight independent LDS reads, once per segment)
+#pragma unroll
+        for (int w = 0; w < 8; ++w) pre[w + 1] = pre[w] + __builtin_amdgcn_readfirstlane(wcnt[w]); // (entries >= NW stay 0)
+        total = pre[8];
+    }
+        MVX_STAMP(1);
+#ifdef MVX_DIAG // 1 = scan, but pretend nothing survived
+        if (P.dbg & 1) total = 0;
+#endif
         return total;
     };
-    auto candidate = [&](int j) -> int { // candidate j of the segment (atom order) -> atom index inside the segment
-        int w = 0;
-        while (j >= wcnt[w]) { // j < total: terminates within NW steps
-            j -= wcnt[w];
-            ++w;
-        }
-        return (int)list[w * SEGW + j];
-    };
-
-    // ---- B1. stage candidates [c0, c0 + n) of the segment: records (exact prep) + channel weights -> LDS rows ----
-    auto stage = [&](int64_t seg0, int c0, int n) {
-        // channel weights of the slots this wave stages (slot = wave + u*NW), all loads in flight
-        unsigned v[8];
-        if (pa.mode == MODE_FEATURES) {
-            const float *feat = static_cast<const float *>(pa.features);
-            const bool wl = lane >= 16 && lane < 16 + CT && (L.cbase + lane - 16) < C;
+    // candidate j of the segment (atom order) -> atom index inside the segment
+    auto candidate = [&](const int (&pre)[9], int j) -> int {
+        if (small) return j;
+        int w = 0, base = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int sl = wave + u * NW;
-                v[u] = 0u;
-                if (sl < n) {
-                    const int64_t a = seg0 + (int64_t)candidate(c0 + sl);
-                    if (wl) v[u] = __float_as_uint(feat[a * C + L.cbase + lane - 16]);
-                }
+        for (int q = 1; q < 8; ++q) {
+            const bool ge = j >= pre[q];
+            w = ge ? q : w;
+            base = ge ? pre[q] : base;
+        }
+        return (int)list[w * SEGW + (j - base)];
+    };
+    // ---- B1. stage candidates [c0, c0 + n) of the segment: records + channel weights -> LDS rows; ends with a barrier
+    auto stage = [&](int64_t seg0, const int (&pre)[9], int c0, int n) {
+    // the atoms of this wave's slots: lane u < 8 <-> slot wave + u*NW (one list read for all eight)
+    int my_idx = 0;
+    {
+        const int sl = wave + lane * NW;
+        if (lane < 8 && sl < n) my_idx = candidate(pre, c0 + sl);
+    }
+    // B1. channel weights of those slots (atom indices broadcast by v_readlane), all loads in flight
+    unsigned v[8];
+    if (pa.mode == MODE_FEATURES) {
+        const float *feat = static_cast<const float *>(pa.features);
+        const bool wl = lane >= 16 && lane < 16 + CT && (cbase + lane - 16) < C;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sl = wave + u * NW;
+            v[u] = 0u;
+            if (sl < n) {
+                const int64_t a = seg0 + (int64_t)__builtin_amdgcn_readlane(my_idx, u);
+                if (wl) v[u] = __float_as_uint(feat[a * C + cbase + lane - 16]);
             }
         }
-        // exact prep of this wave's slots: lane u <-> slot wave + u*NW
-        int my_type = 0;
-        {
-            const int sl = wave + lane * NW;
-            if (lane < 8 && sl < n) {
-                const int64_t a = seg0 + (int64_t)candidate(c0 + sl);
-                double p[3] = {pa.coords[3 * a], pa.coords[3 * a + 1], pa.coords[3 * a + 2]};
-                if (has_xf) apply_xform(xf, p[0], p[1], p[2]);
+    }
+    // the records of this wave's slots
+    int my_type = 0;
+    {
+        const int sl = wave + lane * NW;
+        if (lane < 8 && sl < n) {
+            const int64_t a = seg0 + (int64_t)my_idx;
+            double p[3] = {pa.coords[3 * a], pa.coords[3 * a + 1], pa.coords[3 * a + 2]};
+#ifdef MVX_DIAG
+            if (p[0] != 1.2345e300) MVX_STAMP(7); // (after the coordinates have arrived)
+#endif
+            if (has_xf) apply_xform(xf, p[0], p[1], p[2]);
+            if constexpr (LANE_RANGE) {
+                // per-lane voxel ranges are needed: the prep kernel's own code, one lane per candidate
                 AtomRec R;
                 uint32_t rng[3];
                 bool keep = prep_atom(pa, a, p, rmax32, 0.0, R, rng);
                 my_type = R.type;
-                // the binning pass's filters: x range vs the x-slab, y range in SUBY-voxel slabs, z range in
-                // SUBZ-voxel sub-tiles vs this slab's sub-tiles
                 const int xlo = (int)(rng[0] & 0xffff), xhi = (int)(rng[0] >> 16);
                 const int ylo = (int)(rng[1] & 0xffff) >> SUBY_SH, yhi = (int)(rng[1] >> 16) >> SUBY_SH;
                 const int zlo = (int)(rng[2] & 0xffff) >> SUBZ_SH, zhi = (int)(rng[2] >> 16) >> SUBZ_SH;
@@ -1293,64 +1486,139 @@ __global__ void __launch_bounds__(MAXT, 4)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dst[i] = src[i];
                 pk[sl] = keep ? (((unsigned)zlo << 16) | ((unsigned)zhi << 24)) : EMPTY_ENTRY;
+            } else {
+                // sub-tiles lie inside one reference block: the culls are uniform over this slab (x, y) and
+                // over each wave's sub-tile (z, tested by the waves below); same comparisons as prep_atom
+                const double ub = g.half, lb = -1 * g.half;
+                float r32;
+                double rc;
+                bool keep = true;
+                if (pa.types) {
+                    my_type = pa.types[a];
+                    if (my_type < 0 || my_type >= C) keep = false;
+                }
+                if (pa.radii_src == RAD_SCALAR) {
+                    rc = pa.radius_scalar;
+                    r32 = (float)pa.radius_scalar;
+                    for (int i = 0; i < 3; ++i) keep = keep && (p[i] > lb - rc) && (p[i] < ub + rc); // numpy/voxelizer.py:487-488
+                } else if (pa.radii_src == RAD_CHANNEL_FEATURES) {
+                    r32 = rmax32;
+                    rc = (double)rmax32;
+                    const double lo = (double)((float)lb - rmax32), hi = (double)((float)ub + rmax32); // NEP 50, :138
+                    for (int i = 0; i < 3; ++i) keep = keep && (p[i] > lo) && (p[i] < hi);
+                } else {
+                    const int64_t ri = (pa.radii_src == RAD_ATOM) ? a : (keep ? (int64_t)my_type : -1); // :284-285
+                    r32 = ri >= 0 ? static_cast<const float *>(pa.radii)[ri] : 0.0f;
+                    rc = (double)r32;
+                    for (int i = 0; i < 3; ++i) keep = keep && (p[i] + rc > lb) && (p[i] - rc < ub); // :491-492
+                }
+                // (one python float for every atom: threshold and coefficient come with the launch)
+                const double T = pa.radii_src == RAD_SCALAR ? A.T_scalar : d2_threshold(r32);
+                keep = keep && (T >= 0.0);
+                keep = keep && block_admits(Bx, p[0], rc) && block_admits(By, p[1], rc);
+                const double rrd = (double)r32 * 1.000001 + 1e-9; // conservative window, as prep_atom's
+                keep = keep && (p[0] + rrd >= bx0) && (p[0] - rrd <= bx1) && (p[1] + rrd >= by0) && (p[1] - rrd <= by1);
+                typedef double d2v __attribute__((ext_vector_type(2)));
+                d2v *dst = reinterpret_cast<d2v *>(un + sl * SW);
+                dst[0] = (d2v){p[0], p[1]};
+                dst[1] = (d2v){p[2], T};
+                un[sl * SW + 8] = __float_as_uint(!GAUSS ? 0.0f : (pa.radii_src == RAD_SCALAR ? A.k_scalar : gauss_coeff(r32, pa.sigma32)));
+                un[sl * SW + 9] = (unsigned)my_type;
+                *reinterpret_cast<double *>(un + sl * SW + 10) = rc;
+                // z window radius, rounded up to float; a dropped candidate gets a negative one
+                un[sl * SW + 12] = __float_as_uint(keep ? (float)rrd * 1.0000002f : -1.0f);
             }
         }
+    }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int sl = wave + u * NW;
-            if (sl < n && lane >= 16 && lane < 16 + (CT < 4 ? 4 : CT)) {
-                unsigned w;
-                if (pa.mode == MODE_FEATURES) w = v[u];
-                else if (pa.mode == MODE_TYPES) w = (__builtin_amdgcn_readlane(my_type, u) == L.cbase + lane - 16) ? 0x3f800000u : 0u;
-                else w = (lane == 16) ? 0x3f800000u : 0u;
-                un[sl * SW + lane] = w;
-            }
+    for (int u = 0; u < 8; ++u) {
+        const int sl = wave + u * NW;
+        if (sl < n && lane >= 16 && lane < 16 + (CT < 4 ? 4 : CT)) {
+            unsigned w;
+            if (pa.mode == MODE_FEATURES) w = v[u];
+            else if (pa.mode == MODE_TYPES) w = (__builtin_amdgcn_readlane(my_type, u) == cbase + lane - 16) ? 0x3f800000u : 0u;
+            else w = (lane == 16) ? 0x3f800000u : 0u;
+            un[sl * SW + lane] = w;
         }
-        __syncthreads();
+    }
+    MVX_STAMP(2);
+    __syncthreads();
+    MVX_STAMP(3);
     };
 
-    // The first round of the first segment is staged BEFORE the accumulators exist: the candidate prep (fp64 culls,
-    // thresholds, one lane per candidate) then has the whole register file, and per-molecule calls rarely need more
-    // than this one round per slab. Later rounds / segments run the same code with the accumulators live.
-    int total = 0;
+    // The first round of the first segment is staged BEFORE the accumulators exist: scan and stage then have the
+    // whole register file (with the accumulators live their loops spill, and a scratch reload inside the scan loop
+    // costs a full vmcnt(0) drain per block), and per-molecule calls rarely need more than this one round per slab.
+    // Later rounds / segments run the same code with the accumulators live.
+    int pre0[9];
+    int total0 = 0;
     if (a1 > a0) {
-        total = scan(a0);
-        if (total > 0) stage(a0, 0, total < RW ? total : RW);
+        total0 = scan(a0, pre0);
+        if (total0 > 0) stage(a0, pre0, 0, total0 < RW ? total0 : RW);
     }
-    const bool any = total > 0;
+    // (voxel centres and accumulators only from here on: see above)
+    const LaneCtx L = make_lane_ctx(lane, wave, x0, y0, z0, zt_lo, cbase, P);
     typename Ops::Acc acc;
     Ops::zero(acc);
-    // ---- B2. walk the n staged rows ---------------------------------------------------------------------------
+    bool any = false;
+    // ---- B2. the rows this wave's sub-tile takes (one lane per row), then the walk; ends with a barrier ------------
     auto walk = [&](int n) {
-        const unsigned pkl = lane < n ? pk[lane] : EMPTY_ENTRY;
-        const bool ok = ((int)((pkl >> 16) & 0xff) <= L.zt_w) && ((int)(pkl >> 24) >= L.zt_w);
+    // B2. the rows this wave's sub-tile takes (one lane per row), then the walk
+    {
+        bool ok = false, kept = false;
+        if (lane < n) {
+            if constexpr (LANE_RANGE) {
+                const unsigned pkl = pk[lane];
+                kept = pkl != EMPTY_ENTRY;
+                ok = ((int)((pkl >> 16) & 0xff) <= zt_lo + wave) && ((int)(pkl >> 24) >= zt_lo + wave);
+            } else {
+                const unsigned *r = un + lane * SW;
+                const double pz = *reinterpret_cast<const double *>(r + 4);
+                const double rc = *reinterpret_cast<const double *>(r + 10);
+                const double rr = (double)__uint_as_float(r[12]);
+                const int zv = z0 + SUBZ * wave; // first voxel of this wave's sub-tile
+                const int zl = (zv + SUBZ - 1 < P.D - 1) ? zv + SUBZ - 1 : P.D - 1;
+                const BlockBounds Bz = block_bounds(g, zv);
+                kept = (rr >= 0.0) && (pz + rr >= bz0) && (pz - rr <= bz1);
+                ok = kept && (zv < P.D) && block_admits(Bz, pz, rc) &&
+                     (pz + rr >= (double)zv * P.res - P.half - slack) && (pz - rr <= (double)zl * P.res - P.half + slack);
+            }
+        }
+        any = any || __ballot(kept) != 0ull; // (the same rows in every wave: workgroup-uniform)
         unsigned long long mask = __ballot(ok);
         while (mask) {
             const int sl = __builtin_ctzll(mask);
             mask &= mask - 1;
-            Ops::accumulate(acc, un + sl * SW, L, P, Tc_s - L.cbase, kc_s - L.cbase);
+            Ops::accumulate(acc, un + sl * SW, L, P, Tc_s - cbase, kc_s - cbase);
         }
-        __syncthreads(); // rows / pk consumed before the next round (or the next segment's list) overwrites them
+    }
+    MVX_STAMP(4);
+    __syncthreads(); // rows / pk consumed before the next round (or the next segment's scan strips) overwrite them
     };
-    bool more = false; // candidates beyond the first segment: the zero-fill shortcut of an empty slab no longer applies
-    if (total > 0) {
-        walk(total < RW ? total : RW);
-        for (int c0 = RW; c0 < total; c0 += RW) {
-            const int n = (total - c0) < RW ? (total - c0) : RW;
-            stage(a0, c0, n);
+    if (total0 > 0) {
+        walk(total0 < RW ? total0 : RW);
+#pragma nounroll
+        for (int c0 = RW; c0 < total0; c0 += RW) {
+            const int n = (total0 - c0) < RW ? (total0 - c0) : RW;
+            stage(a0, pre0, c0, n);
             walk(n);
         }
     }
+#pragma nounroll
     for (int64_t seg0 = a0 + SEGN; seg0 < a1; seg0 += SEGN) {
-        const int tot = scan(seg0);
-        more = more || tot > 0;
-        for (int c0 = 0; c0 < tot; c0 += RW) {
-            const int n = (tot - c0) < RW ? (tot - c0) : RW;
-            stage(seg0, c0, n);
+        int pre[9];
+        const int total = scan(seg0, pre);
+#pragma nounroll
+        for (int c0 = 0; c0 < total; c0 += RW) {
+            const int n = (total - c0) < RW ? (total - c0) : RW;
+            stage(seg0, pre, c0, n);
             walk(n);
         }
     }
-    Ops::write(acc, any || more, un, tid, lane, wave, NW, b, L, x0, y0, z0, out, P);
+    MVX_STAMP(5);
+    Ops::write(acc, any, un, tid, lane, wave, NW, b, L, x0, y0, z0, out, P);
+    MVX_STAMP(6);
+#undef MVX_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1493,6 +1761,12 @@ struct DirectFn {
         }
     }
 };
+
+void scalar_radius_constants(double radius_scalar, float sigma32, bool gauss, double *T, float *k) {
+    const float r32 = (float)radius_scalar;
+    *T = d2_threshold(r32);
+    *k = gauss && *T >= 0.0 ? gauss_coeff(r32, sigma32) : 0.0f;
+}
 
 hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, bool chanwise,
                                   bool lane_range, hipStream_t s) {

@@ -17,6 +17,10 @@ from molvoxel_amd import workloads as W
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 name = sys.argv[1]
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+if len(sys.argv) > 3:  # A/B builds: another libmvx_hip.so (path relative to the repo root)
+    from molvoxel_amd.voxelizer.hip import _lib as _l
+
+    _l.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), sys.argv[3])
 pc = np.load(os.path.join(ROOT, "tests", "golden", "pointcloud_10gs.npz"))
 tr, rot = 0.0, False
 if name == "harness":  # test/test_time_numpy.py: 10gs complex, 48^3, C = 10, random transform per call
@@ -36,6 +40,8 @@ else:
     chan = vox.asarray(wl.channels[0], wl.mode)
     radii = wl.radii[0] if np.isscalar(wl.radii[0]) else vox.asarray(wl.radii[0], "radii")
     C_ = wl.num_channels
+if os.environ.get("MVX_DBG"):  # diagnostic builds: run-time ablations of the direct kernel
+    vox.debug_option("dbg", int(os.environ["MVX_DBG"]))
 grid = vox.get_empty_grid(C_)
 for _ in range(20):
     vox.forward(coords, cen, chan, radii, tr, rot, out_grid=grid)
@@ -46,4 +52,11 @@ for _ in range(calls):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
+vox.set_profiling(True)
+for _ in range(200):
+    vox.forward(coords, cen, chan, radii, tr, rot, out_grid=grid)
+torch.cuda.synchronize()
+kt = np.sort(np.array(vox.read_kernel_times_ms())) * 1e3
+vox.set_profiling(False)
+print(f"{name}: main kernel (HIP events) min {kt[0]:.1f} p50 {kt[len(kt) // 2]:.1f} us")
 print(f"{name}: host {1e6 * (t1 - t0) / calls:.1f} us/call, with drain {1e6 * (t2 - t0) / calls:.1f} us/call over {calls} calls")
