@@ -130,13 +130,17 @@ def make_cfg4_shard(total: int, rank: int, world: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=20,
+                    help="untimed steps; the first ~15 launches after an idle period run up to 18 %% slower (clock ramp)")
     ap.add_argument("--workload", choices=("cfg2", "cfg4"), default="cfg2",
                     help="cfg2 = the headline metric (default); cfg4 = 1024 ligands x world size, sharded by atom count")
     ap.add_argument("--batch", type=int, default=256, help="cfg-2 molecules per GPU per step (8.6 GB of grids at 256)")
     ap.add_argument("--ligands-per-gpu", type=int, default=128, help="cfg-4: the job holds this many ligands per rank")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables)")
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="1: mvx_set_overlap - the pre-pass of step k+1 runs under the voxelize launch of step k (the inputs "
+                         "are HBM-resident and complete before the loop, which is that mode's contract); 0: serial calls")
     args = ap.parse_args()
 
     import torch
@@ -162,7 +166,8 @@ def main():
 
     import molvoxel_amd
 
-    vox = molvoxel_amd.create_voxelizer(0.5, 64, "scalar", "gaussian", library="hip", device=dev_index)
+    vox = molvoxel_amd.create_voxelizer(0.5, 64, "scalar", "gaussian", library="hip", device=dev_index,
+                                        overlap_prepass=bool(args.overlap))
     if args.workload == "cfg2":
         B = args.batch
         wl, coords, feats = make_batch(B, rank)
@@ -192,10 +197,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # (event creation takes milliseconds of host time: done before the warm-up, so that the GPU does not sit idle -
+    # and drop its clock - between the warm-up and the timed steps)
+    vox.set_profiling(True)
     for _ in range(args.warmup):
         step()
-    vox.set_profiling(True)
     barrier()
+    vox.read_kernel_times_ms()  # discard the warm-up launches
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -250,6 +258,7 @@ def main():
                 "workload": workload,
                 "molecules_per_gpu_per_step": B,
                 "inputs": "HBM-resident (torch CUDA tensors), outputs left in HBM",
+                "prepass_overlap": bool(args.overlap),
                 "geometry_dtype": "f64",
                 "parallelism": f"{args.gpus} independent ranks, molecules sharded, no collective",
             },
@@ -265,6 +274,7 @@ def main():
                 "kernel_ms_min": float(k[0]),
                 "kernel_ms_p50": float(k[len(k) // 2]),
                 "kernel_ms_max": float(k[-1]),
+                "kernel_ms_list": [round(float(x), 4) for x in kernel_ms],
                 "kernel_launches_timed": len(kernel_ms),
                 "launches_per_step": lps,
                 "molecules_per_launch": B // lps,

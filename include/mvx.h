@@ -119,6 +119,18 @@ int mvx_create(const mvx_config *cfg, mvx_handle **out);
 int mvx_destroy(mvx_handle *h);
 /* Replaces the density_type property setter (base/voxelizer.py:65-70). */
 int mvx_set_density(mvx_handle *h, int32_t density, double sigma);
+/*
+ * Cross-call overlap for loops of large batched calls (no counterpart in the reference, which is synchronous).
+ * A batched call is a pre-pass over the atoms (records, candidate lines: ~7 % of a 256-molecule cfg-2 step) followed
+ * by the voxelize launches. With enable != 0 the handle keeps two workspace sets and runs the pre-pass of call k+1 on
+ * an internal side stream while call k's voxelize launches still occupy the caller's stream; the voxelize launches
+ * of call k+1 follow on the caller's stream as usual, so OUTPUTS keep plain stream-order semantics.
+ * The INPUTS contract changes: the side stream does not wait for the caller's stream, so coords / features / types /
+ * radii must be complete when the call is made (uploaded and synchronised earlier, or produced before a host-side
+ * synchronisation), and must stay unchanged until the call's launches have run - not merely be ordered before the call
+ * on the stream. Applies to MVX_DEVICE inputs and outputs on the batched three-launch path; other calls are unaffected.
+ */
+int mvx_set_overlap(mvx_handle *h, int32_t enable);
 
 /*
  * Batched entry points: B molecules stored back to back, molecule b owning atoms

@@ -49,19 +49,37 @@ struct PinnedSlot {
 };
 
 constexpr int NSLOTS = 4;
-// voxelize_direct_kernel instead of the binned pipeline (run()): one molecule of up to this many atoms ...
-constexpr int64_t DIRECT_MAX_ATOMS_SINGLE = 8192;
-// ... or a batch whose largest molecule has at most this many (one scan round per workgroup)
-constexpr int64_t DIRECT_MAX_ATOMS_BATCH = 256;
+// voxelize_direct_kernel instead of the binned pipeline (run()): launches of at most this many workgroups (two
+// per compute-unit slot: the launch is latency-bound and every launch boundary saved counts; larger launches amortise
+// the binning pre-pass, and their many empty slabs are pure store streams in voxelize_kernel - measured on 256
+// ligands: 2.04 ms direct against 0.64 ms binned) ...
+constexpr long long DIRECT_MAX_WORKGROUPS = 2048;
+// ... whose largest molecule has at most this many atoms (every workgroup scans its molecule's atoms)
+constexpr int64_t DIRECT_MAX_ATOMS = 8192;
 
 } // namespace
+
+// What the binned pipeline's pre-pass writes and its voxelize launches read. Two sets exist so that, with
+// mvx_set_overlap, the pre-pass of call k+1 can fill one set on the side stream while call k's voxelize launches
+// still read the other.
+struct Workspace {
+    DevBuf rec, wbuf, xp, xlist, slist, overflow, meta, aux;
+    std::vector<char> meta_last; // host copy of the offsets the device meta buffer holds
+    bool meta_valid = false;
+    hipEvent_t ev_pre = nullptr; // pre-pass into this set finished (side stream)
+    hipEvent_t ev_vox = nullptr; // the launches reading this set finished (caller's stream)
+    bool vox_recorded = false;
+};
 
 struct mvx_handle {
     mvx_config cfg;
     Geom g;
     float sigma32;
     int device;
-    DevBuf rec, wbuf, xp, xlist, slist, overflow, meta, aux, in_coords, in_chan, in_radii, out_stage;
+    Workspace ws[2];
+    int cur = 0;         // the set the last binned call used
+    bool overlap = false; // mvx_set_overlap
+    DevBuf xf_buf, in_coords, in_chan, in_radii, out_stage, diag;
     PinnedSlot slots[NSLOTS];
     int next_slot = 0;
     std::vector<hipEvent_t> ev; // 2 * MVX_PROFILE_RING events, created on first use
@@ -74,8 +92,6 @@ struct mvx_handle {
     // the cross-stream waits and the extra launch boundaries cost more than the 50 us of pre-pass they hide
     // (0.454 ms/step on one stream, 0.476 with 2 chunks, 0.513 with 4).
     int pipeline = 1;
-    std::vector<char> meta_last; // host copy of the offsets the device meta buffer holds
-    bool meta_valid = false;
     // Stream hand-over: every call reuses the handle's workspace, ordered by the caller's stream. When a call arrives
     // on another stream than the previous one, the new stream first waits for everything the old stream holds
     // (event recorded on the old stream at that moment), so back-to-back calls on different streams never race.
@@ -254,7 +270,7 @@ void resolve_host_centers(mvx_xform *xf, int n) {
 
 // Host-resident arrays go through one pinned slot (a single memcpy each, then async H2D on the caller's stream);
 // device-resident arrays are used where they are. Offsets and transforms always come from the host.
-int stage_inputs(mvx_handle *h, const RunArgs &r, int64_t total, size_t esz, hipStream_t s, DeviceInputs &in) {
+int stage_inputs(mvx_handle *h, Workspace &w, const RunArgs &r, int64_t total, size_t esz, hipStream_t s, DeviceInputs &in) {
     const size_t off_bytes = align_up((size_t)(r.B + 1) * sizeof(int64_t), 16);
     const size_t xf_bytes = r.xforms ? align_up((size_t)r.B * sizeof(mvx_xform), 16) : 0;
     const bool host_in = (r.in_kind == MVX_HOST);
@@ -269,26 +285,26 @@ int stage_inputs(mvx_handle *h, const RunArgs &r, int64_t total, size_t esz, hip
     int rc = acquire_slot(h, off_bytes + xf_bytes + co_bytes + ch_bytes + ra_bytes, &in.slot);
     if (rc) return rc;
     char *pin = in.slot->p;
-    const void *meta_before = h->meta.p;
-    if ((rc = ensure(h->meta, off_bytes + xf_bytes))) return rc;
-    if (h->meta.p != meta_before) h->meta_valid = false;
+    const void *meta_before = w.meta.p;
+    if ((rc = ensure(w.meta, off_bytes + xf_bytes))) return rc;
+    if (w.meta.p != meta_before) w.meta_valid = false;
     // offsets (+ transforms) go to the device only when they differ from what the last call left there
     // (same-shaped batches, the common case in a training loop, skip a 5 us copy kernel)
     const size_t meta_used = (size_t)(r.B + 1) * sizeof(int64_t);
-    const bool meta_same = !r.xforms && h->meta_valid && h->meta_last.size() == meta_used &&
-                           std::memcmp(h->meta_last.data(), r.offsets, meta_used) == 0;
+    const bool meta_same = !r.xforms && w.meta_valid && w.meta_last.size() == meta_used &&
+                           std::memcmp(w.meta_last.data(), r.offsets, meta_used) == 0;
     if (!meta_same) {
         std::memcpy(pin, r.offsets, meta_used);
         if (r.xforms) {
             std::memcpy(pin + off_bytes, r.xforms, (size_t)r.B * sizeof(mvx_xform));
             if (host_in) resolve_host_centers(reinterpret_cast<mvx_xform *>(pin + off_bytes), r.B);
         }
-        HIP_TRY(hipMemcpyAsync(h->meta.p, pin, off_bytes + xf_bytes, hipMemcpyHostToDevice, s));
-        h->meta_last.assign(reinterpret_cast<const char *>(r.offsets), reinterpret_cast<const char *>(r.offsets) + meta_used);
-        h->meta_valid = !r.xforms; // (a later call on another stream waits for this stream first: adopt_stream)
+        HIP_TRY(hipMemcpyAsync(w.meta.p, pin, off_bytes + xf_bytes, hipMemcpyHostToDevice, s));
+        w.meta_last.assign(reinterpret_cast<const char *>(r.offsets), reinterpret_cast<const char *>(r.offsets) + meta_used);
+        w.meta_valid = !r.xforms; // (a later call on another stream waits for this stream first: adopt_stream)
     }
-    in.offsets = reinterpret_cast<const int64_t *>(h->meta.p);
-    in.xforms = r.xforms ? reinterpret_cast<const mvx_xform *>((char *)h->meta.p + off_bytes) : nullptr;
+    in.offsets = reinterpret_cast<const int64_t *>(w.meta.p);
+    in.xforms = r.xforms ? reinterpret_cast<const mvx_xform *>((char *)w.meta.p + off_bytes) : nullptr;
     in.coords = r.coords;
     in.channels = r.channels;
     in.radii = r.radii;
@@ -373,7 +389,40 @@ int run(mvx_handle *h, const RunArgs &r) {
     bool direct = false;
     if (!f64 && sp.NW <= 8 && (long long)r.B * ncc <= 65535) {
         if (h->direct_mode >= 0) direct = h->direct_mode == 1;
-        else direct = (r.B == 1 && total <= DIRECT_MAX_ATOMS_SINGLE) || max_atoms <= DIRECT_MAX_ATOMS_BATCH;
+        else direct = (long long)r.B * ncc * (long long)sp.per_molecule() <= DIRECT_MAX_WORKGROUPS && max_atoms <= DIRECT_MAX_ATOMS;
+    }
+
+    // ---- molecules in chunks (gridDim.y limit; optionally pre-pass on the side stream, one chunk ahead) ----------
+    const int max_mol = 65535 / ncc;
+    int nchunk = (r.B + max_mol - 1) / max_mol;
+    if (h->pipeline > 1 && r.B >= 4 * h->pipeline) nchunk = std::max(nchunk, h->pipeline);
+    // Cross-call overlap (mvx_set_overlap): this call's pre-pass fills the other workspace set on the side stream,
+    // under the previous call's voxelize launches. Device-resident inputs and outputs only.
+    const bool overlap = h->overlap && !direct && nchunk == 1 && r.in_kind == MVX_DEVICE && r.out_kind == MVX_DEVICE;
+    if (overlap) h->cur ^= 1;
+    Workspace &w = h->ws[h->cur];
+    const bool side_stream = (nchunk > 1) || overlap;
+    hipStream_t pre = s;
+    if (side_stream) {
+        if (!h->side) { // lowest priority: the pre-pass should take the slots the voxelize launch leaves, not compete
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
+        }
+        if (!h->ev_in) HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+        pre = h->side;
+    }
+    if (overlap) {
+        if (!w.ev_pre) HIP_TRY(hipEventCreateWithFlags(&w.ev_pre, hipEventDisableTiming));
+        if (!w.ev_vox) HIP_TRY(hipEventCreateWithFlags(&w.ev_vox, hipEventDisableTiming));
+        // this set was last read by the call before the previous one: its launches must have drained. (Nothing makes
+        // the side stream wait for the caller's stream otherwise: that is the caller's promise about the inputs.)
+        if (w.vox_recorded) {
+            HIP_TRY(hipStreamWaitEvent(pre, w.ev_vox, 0));
+        } else { // first use of the set: order behind everything the caller's stream holds so far
+            HIP_TRY(hipEventRecord(h->ev_in, s));
+            HIP_TRY(hipStreamWaitEvent(pre, h->ev_in, 0));
+        }
     }
 
     DeviceInputs in;
@@ -381,7 +430,7 @@ int run(mvx_handle *h, const RunArgs &r) {
         in.coords = r.coords;
         in.channels = r.channels;
         in.radii = r.radii;
-    } else if ((rc = stage_inputs(h, r, total, esz, s, in))) {
+    } else if ((rc = stage_inputs(h, w, r, total, esz, overlap ? pre : s, in))) {
         return rc;
     }
     void *d_out = r.out;
@@ -398,16 +447,16 @@ int run(mvx_handle *h, const RunArgs &r) {
     const size_t nslabs = (size_t)r.B * sp.per_molecule();
     if (nslabs * (size_t)ncc + 1 > (size_t)0x7fffffff) return fail(MVX_ERR_INVALID, "batch too large for one call");
     if (!direct) {
-        if ((rc = ensure(h->rec, n_alloc * sizeof(AtomRec)))) return rc;
-        if (!direct_w && (rc = ensure(h->wbuf, n_alloc * (size_t)Cpad * esz))) return rc;
-        if ((rc = ensure(h->xp, n_alloc * sizeof(uint2)))) return rc;
+        if ((rc = ensure(w.rec, n_alloc * sizeof(AtomRec)))) return rc;
+        if (!direct_w && (rc = ensure(w.wbuf, n_alloc * (size_t)Cpad * esz))) return rc;
+        if ((rc = ensure(w.xp, n_alloc * sizeof(uint2)))) return rc;
         // x-lists: packed regions, (sum(N) + 2*B) * nsx entries; slab lines: primary + extension entries per slab
-        if ((rc = ensure(h->xlist, ((size_t)total + 2 * (size_t)r.B) * sp.nsx * sizeof(uint2)))) return rc;
-        if ((rc = ensure(h->slist, nslabs * (SLAB_LINE_ENTRIES + SLAB_EXT_ENTRIES) * sizeof(uint2)))) return rc;
-        if ((rc = ensure(h->overflow, (nslabs * (size_t)ncc + 1) * sizeof(int)))) return rc;
+        if ((rc = ensure(w.xlist, ((size_t)total + 2 * (size_t)r.B) * sp.nsx * sizeof(uint2)))) return rc;
+        if ((rc = ensure(w.slist, nslabs * (SLAB_LINE_ENTRIES + SLAB_EXT_ENTRIES) * sizeof(uint2)))) return rc;
+        if ((rc = ensure(w.overflow, (nslabs * (size_t)ncc + 1) * sizeof(int)))) return rc;
     }
-    uint2 *d_xlist = reinterpret_cast<uint2 *>(h->xlist.p);
-    uint2 *d_slist = reinterpret_cast<uint2 *>(h->slist.p);
+    uint2 *d_xlist = reinterpret_cast<uint2 *>(w.xlist.p);
+    uint2 *d_slist = reinterpret_cast<uint2 *>(w.slist.p);
     uint2 *d_slist_ext = d_slist ? d_slist + nslabs * SLAB_LINE_ENTRIES : nullptr; // extension lines live behind the primary lines
 
     const bool gauss = (h->cfg.density == MVX_GAUSSIAN);
@@ -417,15 +466,15 @@ int run(mvx_handle *h, const RunArgs &r) {
     float *d_kc = nullptr;
     if (chanwise && !direct) {
         const size_t tc_off = 16, kc_off = tc_off + align_up((size_t)r.C * sizeof(double), 16);
-        if ((rc = ensure(h->aux, kc_off + (size_t)r.C * sizeof(float)))) return rc;
-        d_rmax = h->aux.p;
-        d_Tc = reinterpret_cast<double *>((char *)h->aux.p + tc_off);
-        d_kc = reinterpret_cast<float *>((char *)h->aux.p + kc_off);
+        if ((rc = ensure(w.aux, kc_off + (size_t)r.C * sizeof(float)))) return rc;
+        d_rmax = w.aux.p;
+        d_Tc = reinterpret_cast<double *>((char *)w.aux.p + tc_off);
+        d_kc = reinterpret_cast<float *>((char *)w.aux.p + kc_off);
         if (f64)
-            HIP_TRY(launch_chan_aux64(static_cast<const double *>(in.radii), r.C, static_cast<double *>(d_rmax), d_Tc, s));
+            HIP_TRY(launch_chan_aux64(static_cast<const double *>(in.radii), r.C, static_cast<double *>(d_rmax), d_Tc, overlap ? pre : s));
         else
             HIP_TRY(launch_chan_aux(static_cast<const float *>(in.radii), r.C, h->cfg.density, h->sigma32,
-                                    static_cast<float *>(d_rmax), d_Tc, d_kc, s));
+                                    static_cast<float *>(d_rmax), d_Tc, d_kc, overlap ? pre : s));
     }
 
     // ---- kernel arguments -------------------------------------------------------------------------
@@ -451,13 +500,13 @@ int run(mvx_handle *h, const RunArgs &r) {
     pa.density = h->cfg.density;
     pa.sigma32 = h->sigma32;
     pa.g = g;
-    pa.rec = reinterpret_cast<AtomRec *>(h->rec.p);
-    pa.wbuf = direct_w ? nullptr : h->wbuf.p;
-    pa.xp = reinterpret_cast<uint2 *>(h->xp.p);
+    pa.rec = reinterpret_cast<AtomRec *>(w.rec.p);
+    pa.wbuf = direct_w ? nullptr : w.wbuf.p;
+    pa.xp = reinterpret_cast<uint2 *>(w.xp.p);
 
     VoxArgs va;
-    va.rec = reinterpret_cast<const unsigned *>(h->rec.p);
-    va.w = reinterpret_cast<const unsigned *>(direct_w ? in.channels : h->wbuf.p);
+    va.rec = reinterpret_cast<const unsigned *>(w.rec.p);
+    va.w = reinterpret_cast<const unsigned *>(direct_w ? in.channels : w.wbuf.p);
     va.xlist = d_xlist;
     va.slist = d_slist;
     va.slist_ext = d_slist_ext;
@@ -465,7 +514,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.Tc = d_Tc;
     va.kc = d_kc;
     va.out = d_out;
-    va.overflow = reinterpret_cast<int *>(h->overflow.p);
+    va.overflow = reinterpret_cast<int *>(w.overflow.p);
     va.p.res = g.res;
     va.p.half = g.half;
     va.p.D = D;
@@ -499,8 +548,8 @@ int run(mvx_handle *h, const RunArgs &r) {
         da.pa = pa;
         da.pa.rec = nullptr;
 #ifdef MVX_DIAG // stamps of every workgroup (8 x 8 B each), read back with mvx_debug_read_records
-        if ((rc = ensure(h->rec, nslabs * (size_t)ncc * 64))) return rc;
-        da.pa.rec = reinterpret_cast<AtomRec *>(h->rec.p);
+        if ((rc = ensure(w.rec, nslabs * (size_t)ncc * 64))) return rc;
+        da.pa.rec = reinterpret_cast<AtomRec *>(w.rec.p);
 #endif
         da.pa.wbuf = nullptr;
         da.pa.xp = nullptr;
@@ -533,21 +582,13 @@ int run(mvx_handle *h, const RunArgs &r) {
         return MVX_OK;
     }
 
-    // ---- launches: molecules in chunks (gridDim.y limit; optionally pre-pass on the side stream, one chunk ahead) ----
-    const int max_mol = 65535 / ncc;
-    int nchunk = (r.B + max_mol - 1) / max_mol;
-    if (h->pipeline > 1 && r.B >= 4 * h->pipeline) nchunk = std::max(nchunk, h->pipeline);
-    const bool side_stream = (nchunk > 1);
-    hipStream_t pre = s;
-    if (side_stream) {
-        if (!h->side) HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-        if (!h->ev_in) HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+    // ---- launches -----------------------------------------------------------------------------------------------
+    if (side_stream && !overlap) {
         while ((int)h->ev_pre.size() < nchunk) {
             hipEvent_t e = nullptr;
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             h->ev_pre.push_back(e);
         }
-        pre = h->side;
         // inputs (and the workspace, still read by the previous call's launches) are ready once `s` gets here
         HIP_TRY(hipEventRecord(h->ev_in, s));
         HIP_TRY(hipStreamWaitEvent(pre, h->ev_in, 0));
@@ -561,15 +602,15 @@ int run(mvx_handle *h, const RunArgs &r) {
         // (the first launch also zeroes the overflow counter)
         HIP_TRY(launch_xbin(pa.xp, in.offsets, b0, b1 - b0, max_atoms, sp.nsx, sp.nsy, sp.nzc, sp.NW, d_xlist, d_slist,
                             d_slist_ext, k == 0 ? va.overflow : nullptr, pre));
-        if (side_stream) HIP_TRY(hipEventRecord(h->ev_pre[k], pre));
+        if (side_stream) HIP_TRY(hipEventRecord(overlap ? w.ev_pre : h->ev_pre[k], pre));
     }
     if (f64) { // float64 grids: one launch of the general slab loop over the whole batch
-        for (int k = 0; k < nchunk && side_stream; ++k) HIP_TRY(hipStreamWaitEvent(s, h->ev_pre[k], 0));
+        for (int k = 0; k < nchunk && side_stream; ++k) HIP_TRY(hipStreamWaitEvent(s, overlap ? w.ev_pre : h->ev_pre[k], 0));
         if ((rc = timed_launch(h, s, [&] { return launch_voxelize64(va, ct, gauss, chanwise, lane_range, s); }))) return rc;
     } else {
         for (int k = 0; k < nchunk; ++k) {
             const int b0 = chunk_begin(k), b1 = chunk_begin(k + 1);
-            if (side_stream) HIP_TRY(hipStreamWaitEvent(s, h->ev_pre[k], 0));
+            if (side_stream) HIP_TRY(hipStreamWaitEvent(s, overlap ? w.ev_pre : h->ev_pre[k], 0));
             va.p.b0 = b0;
             // the bracket holds voxelize_kernel alone (what rocprofv3 reports under that name)
             if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, ct, gauss, chanwise, lane_range, s); }))) return rc;
@@ -578,6 +619,12 @@ int run(mvx_handle *h, const RunArgs &r) {
         if (max_atoms >= std::min(8 * sp.NW, 64)) HIP_TRY(launch_voxelize_dense(va, ct, gauss, chanwise, lane_range, s));
     }
 
+    if (overlap) { // the next call but one refills this set
+        HIP_TRY(hipEventRecord(w.ev_vox, s));
+        w.vox_recorded = true;
+    } else {
+        w.vox_recorded = false; // (its reads are ordered on the caller's stream only)
+    }
     HIP_TRY(hipEventRecord(in.slot->done, s));
     in.slot->in_flight = true;
 
@@ -652,7 +699,12 @@ int mvx_destroy(mvx_handle *h) {
     if (!h) return MVX_OK;
     DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&h->rec, &h->wbuf, &h->xp, &h->xlist, &h->slist, &h->overflow, &h->meta, &h->aux, &h->in_coords, &h->in_chan, &h->in_radii, &h->out_stage};
+    std::vector<DevBuf *> bufs = {&h->xf_buf, &h->in_coords, &h->in_chan, &h->in_radii, &h->out_stage};
+    for (Workspace &w : h->ws) {
+        for (DevBuf *b : {&w.rec, &w.wbuf, &w.xp, &w.xlist, &w.slist, &w.overflow, &w.meta, &w.aux}) bufs.push_back(b);
+        if (w.ev_pre) (void)hipEventDestroy(w.ev_pre);
+        if (w.ev_vox) (void)hipEventDestroy(w.ev_vox);
+    }
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (PinnedSlot &s : h->slots) {
@@ -677,6 +729,12 @@ int mvx_set_density(mvx_handle *h, int32_t density, double sigma) {
         h->cfg.sigma = sigma;
         h->sigma32 = (float)sigma;
     }
+    return MVX_OK;
+}
+
+int mvx_set_overlap(mvx_handle *h, int32_t enable) {
+    if (!h) return fail(MVX_ERR_INVALID, "null handle");
+    h->overlap = enable != 0;
     return MVX_OK;
 }
 
@@ -744,11 +802,10 @@ int mvx_transform_coords(mvx_handle *h, const double *coords, int64_t N, const m
     PinnedSlot *slot = nullptr;
     int rc = acquire_slot(h, xf_bytes + (host_in ? co_bytes : 0), &slot);
     if (rc) return rc;
-    if ((rc = ensure(h->meta, xf_bytes))) return rc;
-    h->meta_valid = false; // the buffer now holds a transform, not batch offsets
+    if ((rc = ensure(h->xf_buf, xf_bytes))) return rc;
     std::memcpy(slot->p, xform, sizeof(mvx_xform));
     if (host_in) resolve_host_centers(reinterpret_cast<mvx_xform *>(slot->p), 1);
-    HIP_TRY(hipMemcpyAsync(h->meta.p, slot->p, xf_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->xf_buf.p, slot->p, xf_bytes, hipMemcpyHostToDevice, s));
     const double *d_in = coords;
     if (host_in) {
         if ((rc = ensure(h->in_coords, co_bytes))) return rc;
@@ -761,7 +818,7 @@ int mvx_transform_coords(mvx_handle *h, const double *coords, int64_t N, const m
         if ((rc = ensure(h->out_stage, co_bytes))) return rc;
         d_out = reinterpret_cast<double *>(h->out_stage.p);
     }
-    HIP_TRY(launch_transform(d_in, N, reinterpret_cast<const mvx_xform *>(h->meta.p), d_out, s));
+    HIP_TRY(launch_transform(d_in, N, reinterpret_cast<const mvx_xform *>(h->xf_buf.p), d_out, s));
     HIP_TRY(hipEventRecord(slot->done, s));
     slot->in_flight = true;
     if (host_out) {
@@ -810,11 +867,12 @@ int mvx_last_kernel_ms(mvx_handle *h, float *ms) {
 
 int mvx_debug_read_records(mvx_handle *h, void *host_dst, int64_t n, void *stream) {
     if (!h || !host_dst || n < 0) return fail(MVX_ERR_INVALID, "bad argument");
-    if ((size_t)n * sizeof(AtomRec) > h->rec.cap) return fail(MVX_ERR_INVALID, "more records requested than the workspace holds");
+    const DevBuf &rec = h->ws[h->cur].rec;
+    if ((size_t)n * sizeof(AtomRec) > rec.cap) return fail(MVX_ERR_INVALID, "more records requested than the workspace holds");
     if (n == 0) return MVX_OK;
     DeviceGuard guard(h->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemcpyAsync(host_dst, h->rec.p, (size_t)n * sizeof(AtomRec), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(host_dst, rec.p, (size_t)n * sizeof(AtomRec), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return MVX_OK;
 }
@@ -827,10 +885,28 @@ int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
     else if (n == "direct") h->direct_mode = value < 0 ? -1 : (value ? 1 : 0);
 #ifdef MVX_DIAG
     else if (n == "dbg") h->dbg = value;
+    else if (n == "vk_stamps") { // value = workgroups to make room for (0: off); read back with mvx_debug_read_diag
+        DeviceGuard guard(h->device);
+        if (value > 0) {
+            if (int rc = ensure(h->diag, (size_t)value * 128)) return rc;
+            HIP_TRY(hipMemset(h->diag.p, 0, (size_t)value * 128));
+        }
+        HIP_TRY(set_diag_buffer(value > 0 ? h->diag.p : nullptr));
+    }
 #endif
     else return fail(MVX_ERR_INVALID, "unknown option: " + n);
     return MVX_OK;
 }
+
+#ifdef MVX_DIAG
+extern "C" int mvx_debug_read_diag(mvx_handle *h, void *host_dst, int64_t bytes) {
+    if (!h || !host_dst || bytes < 0 || (size_t)bytes > h->diag.cap) return fail(MVX_ERR_INVALID, "bad argument");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_dst, h->diag.p, (size_t)bytes, hipMemcpyDeviceToHost));
+    return MVX_OK;
+}
+#endif
 
 int mvx_alloc(mvx_handle *h, int64_t bytes, void **ptr) {
     if (!h || !ptr || bytes < 0) return fail(MVX_ERR_INVALID, "bad argument");

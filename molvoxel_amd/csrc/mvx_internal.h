@@ -133,6 +133,9 @@ hipError_t launch_voxelize_dense(const VoxArgs &a, int32_t ct, bool gauss, bool 
 hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, bool chanwise,
                                   bool lane_range, hipStream_t s);
 void scalar_radius_constants(double radius_scalar, float sigma32, bool gauss, double *T, float *k);
+#ifdef MVX_DIAG
+hipError_t set_diag_buffer(void *p);
+#endif
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW);
 int32_t voxelize_dcap(int32_t ct, int32_t NW);
 

@@ -41,6 +41,16 @@ namespace mvx {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
+#ifdef MVX_DIAG
+// Diagnostic builds (tools/ab_build.sh diag "-DMVX_DIAG"): s_memtime stamps of the batched voxelize_kernel, 16 x 8 B per
+// workgroup, into a buffer the host hands over with set_diag_buffer(); the shipped library has none of this.
+__device__ unsigned long long *g_diag = nullptr;
+#define VK_STAMP(i) do { if (g_diag && lane == 0 && (wave == 0 || (i) >= 8)) g_diag[16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+hipError_t set_diag_buffer(void *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_diag), &p, sizeof(p)); }
+#else
+#define VK_STAMP(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
@@ -832,6 +842,8 @@ __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], b
 #pragma unroll
     for (int rd = 0; rd < NROUND; ++rd) {
         __syncthreads(); // candidate rows (round 0) / previous tile (later rounds) fully consumed
+        if (rd == 0) VK_STAMP(4); // every wave's walk is done
+        if (rd == 1) VK_STAMP(5); // round 0 transposed and its stores issued
 #pragma unroll
         for (int c = 0; c < CR; ++c) {
             const int cg = rd * CR + c;
@@ -1001,7 +1013,9 @@ __device__ __forceinline__ void line_round(typename Ops::Acc &acc, const uint2 E
         const int sl = wave + u * NW;
         if (sl < RW && e0 + sl >= 1 && e0 + sl <= n_line && stager) un[sl * SW + lane] = v[u];
     }
+    VK_STAMP(2);
     __syncthreads();
+    VK_STAMP(3);
     const unsigned pk = Er.y;
     const bool ok = (lane < RW) && (e0 + lane >= 1) && (e0 + lane <= n_line) && ((int)((pk >> 16) & 0xff) <= L.zt_w) &&
                     ((int)(pk >> 24) >= L.zt_w);
@@ -1011,6 +1025,7 @@ __device__ __forceinline__ void line_round(typename Ops::Acc &acc, const uint2 E
         mask &= mask - 1;
         Ops::accumulate(acc, un + sl * SW, L, P, Tc, kc);
     }
+    VK_STAMP(8 + wave); // every wave's own walk end
 }
 
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
@@ -1043,8 +1058,10 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     typename Ops::Acc acc;
     Ops::zero(acc);
 
+    VK_STAMP(0);
     const unsigned n_hdr = (unsigned)__builtin_amdgcn_readlane((int)E.x, 0);
     const int64_t a0 = (int64_t)(unsigned)__builtin_amdgcn_readlane((int)E.y, 0);
+    VK_STAMP(1); // the line has arrived
     const int RW = 8 * NW < 64 ? 8 * NW : 64; // rows this kernel can stage
     if (n_hdr >= (unsigned)RW) { // includes LINE_OVERFLOW: dense slab, left to voxelize_dense_kernel
         if (tid == 0) {
@@ -1055,6 +1072,10 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     }
     if (n_hdr > 0) line_round<Ops>(acc, E, 0, (int)n_hdr, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
     Ops::write(acc, n_hdr > 0, un, tid, lane, wave, NW, b, L, x0, y0, z0, out, P);
+    VK_STAMP(6); // all stores issued
+#ifdef MVX_DIAG
+    if (g_diag && tid == 0) g_diag[16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 7] = n_hdr;
+#endif
 }
 
 // The general slab loop. float32: over the overflow list of the voxelize_kernel launches. float64: `overflow` is

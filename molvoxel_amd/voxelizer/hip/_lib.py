@@ -52,6 +52,7 @@ SIGNATURES = {
     "mvx_create": (C.c_int, [C.POINTER(MvxConfig), C.POINTER(Handle)]),
     "mvx_destroy": (C.c_int, [Handle]),
     "mvx_set_density": (C.c_int, [Handle, _i32, _dbl]),
+    "mvx_set_overlap": (C.c_int, [Handle, _i32]),
     "mvx_forward_features_batch": (C.c_int, [Handle, _vp, _vp, _vp, _dbl, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
     "mvx_forward_types_batch": (C.c_int, [Handle, _vp, _vp, _vp, _dbl, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
     "mvx_forward_single_batch": (C.c_int, [Handle, _vp, _vp, _dbl, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),

@@ -56,6 +56,7 @@ class Voxelizer(BaseVoxelizer):
         blockdim: int | None = None,
         device=None,
         output: str = "torch",
+        overlap_prepass: bool = False,
         **kwargs,
     ):
         super().__init__(resolution, dimension, radii_type, density_type, **kwargs)
@@ -88,6 +89,16 @@ class Voxelizer(BaseVoxelizer):
             0,
         )
         _lib.check(self._lib.mvx_create(C.byref(cfg), C.byref(self._handle)))
+        self.overlap_prepass = bool(overlap_prepass)
+        if self.overlap_prepass:
+            self.set_overlap_prepass(True)
+
+    def set_overlap_prepass(self, enable: bool):
+        """Loops of large `forward_batch` calls: run the pre-pass of call k+1 under the voxelize launches of call k
+        (mvx_set_overlap). The caller then promises that the input tensors of a call are complete when the call is made
+        (not merely ordered on the stream) and stay unchanged until its launches have run; outputs keep stream order."""
+        _lib.check(self._lib.mvx_set_overlap(self._handle, 1 if enable else 0))
+        self.overlap_prepass = bool(enable)
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -161,7 +172,7 @@ class Voxelizer(BaseVoxelizer):
         if idx != self._device_index:
             kw = {"sigma": self._sigma} if self.is_density_type_gaussian else {}
             return type(self)(self._resolution, self._dimension, self._radii_type, self._density_type, self.precision,
-                              self.blockdim, idx, self.output, **kw)
+                              self.blockdim, idx, self.output, self.overlap_prepass, **kw)
         return self
 
     def cuda(self):

@@ -749,3 +749,46 @@ def test_forward_batch_rejects_short_arrays(mv):
     # fewer radii than channels is fine for types as long as every type has one (extra channels stay zero)
     out = v.forward_batch(xyz, off, None, rng.integers(0, 3, 30), np.ones(3, np.float32), num_channels=5)
     assert out.shape == (2, 5, 16, 16, 16) and not out[:, 3:].any()
+
+
+def test_overlapped_prepass_equals_serial_calls(mv):
+    """mvx_set_overlap: the pre-pass of call k+1 runs on the side stream under call k's voxelize launches, on the
+    other workspace set. A loop of batched calls with changing inputs, offsets, operators and radii kinds - and no host
+    synchronisation between calls - must give exactly the grids of the serial handle."""
+    import torch
+
+    rng = np.random.default_rng(99)
+    D = 32
+    W_ = 0.5 * (D - 1)
+
+    def make(sizes, mode, C_):
+        coords = rng.uniform(-W_ / 2 - 1, W_ / 2 + 1, (sum(sizes), 3))
+        chan = rng.random((sum(sizes), C_)).astype(np.float32) if mode == "features" else rng.integers(0, C_, sum(sizes))
+        return coords, chan, np.cumsum([0] + sizes)
+
+    jobs = [make([700, 900, 40, 0, 1300, 800, 650, 2000, 300, 1100, 5, 900], "features", 8),
+            make([1500, 600, 700, 900, 40, 1300, 800, 650, 2000, 300, 1100, 400], "features", 8),
+            make([300, 200, 400, 900, 100, 1300, 800, 650, 600, 300, 1100, 700], "types", 5),
+            make([2500] + [350] * 11, "features", 33)]
+    for radii_type in ("scalar", "atom-wise", "channel-wise"):
+        serial = mv.create_voxelizer(0.5, D, radii_type, "gaussian", "hip", sigma=0.6)
+        fast = mv.create_voxelizer(0.5, D, radii_type, "gaussian", "hip", sigma=0.6, overlap_prepass=True)
+        for v in (serial, fast):
+            v.debug_option("direct", 0)
+        dev = []
+        for coords, chan, off in jobs:
+            C_ = chan.shape[1] if chan.ndim == 2 else int(chan.max()) + 1
+            radii = {"scalar": 1.2, "atom-wise": serial.asarray(rng.uniform(0.8, 1.7, coords.shape[0]), "radii"),
+                     "channel-wise": serial.asarray(rng.uniform(0.8, 1.7, C_), "radii")}[radii_type]
+            dev.append((serial.asarray(coords, "coords"), serial.asarray(chan, "features" if chan.ndim == 2 else "types"), off, radii, C_))
+        torch.cuda.synchronize()  # the inputs are complete before the loop starts: the overlap contract
+        order = [0, 1, 0, 2, 3, 3, 1, 2, 0, 0, 3, 1]
+        want = [serial.forward_batch(dev[j][0], dev[j][2], None, dev[j][1], dev[j][3], num_channels=dev[j][4]).clone() for j in order]
+        got = [fast.forward_batch(dev[j][0], dev[j][2], None, dev[j][1], dev[j][3], num_channels=dev[j][4]).clone() for j in order]
+        torch.cuda.synchronize()
+        for k, (a, b) in enumerate(zip(want, got)):
+            assert torch.equal(a, b), (radii_type, k, order[k])
+        # a single-molecule call (direct kernel) and a transform in between do not disturb the sets
+        one = fast.forward_features(dev[0][0][:700], None, dev[0][1][:700], dev[0][3] if radii_type != "atom-wise" else dev[0][3][:700])
+        assert torch.equal(one, want[0][0])
+        assert torch.equal(fast.forward_batch(dev[1][0], dev[1][2], None, dev[1][1], dev[1][3], num_channels=dev[1][4]), want[1])
