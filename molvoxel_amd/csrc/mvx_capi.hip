@@ -466,12 +466,13 @@ int run(mvx_handle *h, const RunArgs &r) {
     float *d_kc = nullptr;
     if (chanwise && !direct) {
         const size_t tc_off = 16, kc_off = tc_off + align_up((size_t)r.C * sizeof(double), 16);
-        if ((rc = ensure(w.aux, kc_off + (size_t)r.C * sizeof(float)))) return rc;
+        if ((rc = ensure(w.aux, kc_off + (size_t)r.C * sizeof(double)))) return rc; // (float64 handles: double coefficients)
         d_rmax = w.aux.p;
         d_Tc = reinterpret_cast<double *>((char *)w.aux.p + tc_off);
         d_kc = reinterpret_cast<float *>((char *)w.aux.p + kc_off);
         if (f64)
-            HIP_TRY(launch_chan_aux64(static_cast<const double *>(in.radii), r.C, static_cast<double *>(d_rmax), d_Tc, overlap ? pre : s));
+            HIP_TRY(launch_chan_aux64(static_cast<const double *>(in.radii), r.C, h->cfg.density, h->cfg.sigma,
+                                      static_cast<double *>(d_rmax), d_Tc, reinterpret_cast<double *>(d_kc), overlap ? pre : s));
         else
             HIP_TRY(launch_chan_aux(static_cast<const float *>(in.radii), r.C, h->cfg.density, h->sigma32,
                                     static_cast<float *>(d_rmax), d_Tc, d_kc, overlap ? pre : s));
@@ -499,6 +500,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     else pa.radii_src = chanwise ? RAD_CHANNEL_FEATURES : RAD_CHANNEL_BY_TYPE;
     pa.density = h->cfg.density;
     pa.sigma32 = h->sigma32;
+    pa.sigma64 = h->cfg.sigma;
     pa.g = g;
     pa.rec = reinterpret_cast<AtomRec *>(w.rec.p);
     pa.wbuf = direct_w ? nullptr : w.wbuf.p;
@@ -532,7 +534,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.dcap = f64 ? 64 : voxelize_dcap(ct, sp.NW);
     // 16-B stores need whole float4 groups per row (D % 4 == 0) and a 16-B aligned grid; anything else (odd
     // dimensions, a slice `grid[i]` of a batch grid whose slices are not 16-B multiples) takes the scalar-store path
-    va.p.vec_store = (D % 4 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) ? 1 : 0;
+    va.p.vec_store = (D % (f64 ? 2 : 4) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) ? 1 : 0;
     va.p.store_kind = h->store_kind;
     va.p.pace = (nslabs * (size_t)ncc > 4096) ? 1 : 0;
     va.p.sigma = h->cfg.sigma;

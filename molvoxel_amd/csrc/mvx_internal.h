@@ -21,11 +21,12 @@ constexpr int RPC = SUBX * SUBY; // tile rows per channel
 struct __attribute__((aligned(16))) AtomRec {
     double px, py, pz; // coordinates after centring / transform (fp64, reference op order)
     double T;          // membership threshold on d2: contributes iff d2 <= T (exact restatement of
-                       // float32(float32(sqrt(d2))/r) <= 1); negative = never
+                       // float32(float32(sqrt(d2))/r) <= 1, or of sqrt(d2)/r <= 1 in float64 for float64 grids);
+                       // negative = never
     float k;           // gaussian: value = exp2(k * d2), k = -0.5*log2(e)/(r*sigma)^2
     int32_t type;      // forward_types channel
     uint32_t xr, yr, zr; // admitted voxel index range per axis, lo | hi << 16 (inclusive); 0x0000ffff = empty
-    uint32_t pad[3];
+    uint32_t pad[3];   // float64 grids: pad[1..2] = the float64 gaussian coefficient (exp(c * d2))
 };
 static_assert(sizeof(AtomRec) == 64, "AtomRec must be 64 bytes");
 
@@ -63,6 +64,7 @@ struct PrepArgs {
     int32_t radii_src;
     int32_t density;
     float sigma32;
+    double sigma64;    // the Gaussian sigma as the reference holds it (python float): float64 grids
     Geom g;
     AtomRec *rec;      // per-atom records
     void *wbuf;        // packed channel weights (Cpad per atom: features zero padded / one-hot type / 1), or null when
@@ -115,7 +117,8 @@ struct VoxArgs {
 // launchers (host side, mvx_kernels.hip)
 hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax,
                            double *Tc, float *kc, hipStream_t s);
-hipError_t launch_chan_aux64(const double *radii, int32_t C, double *rmax, double *Rc, hipStream_t s);
+hipError_t launch_chan_aux64(const double *radii, int32_t C, int32_t density, double sigma, double *rmax, double *Tc, double *kc,
+                             hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
 hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int32_t b0, int32_t nb, int64_t max_atoms, int32_t nsx, int32_t nsy,
                        int32_t nzc, int32_t NW, uint2 *xlist, uint2 *slist, uint2 *slist_ext, int *zero_counter, hipStream_t s);

@@ -87,6 +87,25 @@ __host__ __device__ double d2_threshold(float r32) {
     return (lo >= 0.0) ? hi : next_down(hi);
 }
 
+// float64 grids: largest fp64 d2 with sqrt_f64(d2) / r <= 1 evaluated in float64 as the reference does
+// (numpy/voxelizer.py:548-555 with fp = float64). fl(s / r) <= 1 <=> s <= r for doubles s, r > 0 (s > r puts the quotient
+// at least one ulp(r)/r > 2^-53 above 1, which rounds above 1), and fl(sqrt(d2)) <= r <=> d2 < (r + ulp(r)/2)^2 =
+// r * nextup(r) + ulp^2/4: the same product-and-residual test as above with y = r.
+__host__ __device__ __forceinline__ double d2_threshold64(double r) {
+    if (!(r > 0.0) || !(r < 1.0e300)) return -1.0;
+    const double rp = next_up(r);
+    const double hi = r * rp;
+    const double lo = fma(r, rp, -hi);
+    return (lo >= 0.0) ? hi : next_down(hi);
+}
+// float64 gaussian: exp(-0.5 * ((d / r) / sigma)^2) = exp(c * d2), c = -0.5 / (r sigma)^2. One rounding chain instead of
+// the reference's sqrt, two divisions and a square: both are within ~4 ulp of the exact argument (|arg| <= 0.5/sigma^2),
+// i.e. the values agree to ~1e-15 relative.
+__host__ __device__ __forceinline__ double gauss_coeff64(double r, double sigma) {
+    const double rs = r * sigma;
+    return -0.5 / (rs * rs);
+}
+
 __host__ __device__ __forceinline__ float gauss_coeff(float r32, float sigma32) {
     const double rs = (double)r32 * (double)sigma32;
     return (float)(-0.5 * 1.4426950408889634 / (rs * rs));
@@ -226,8 +245,11 @@ __global__ void chan_aux_kernel(const float *radii, int C, int density, float si
 }
 
 // float64 grids: the per-channel radii themselves (the kernel divides by them) and their maximum, in float64
-__global__ void chan_aux64_kernel(const double *radii, int C, double *rmax, double *Rc) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) Rc[c] = radii[c];
+__global__ void chan_aux64_kernel(const double *radii, int C, int density, double sigma, double *rmax, double *Tc, double *kc) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        Tc[c] = d2_threshold64(radii[c]);
+        kc[c] = (density == MVX_GAUSSIAN && Tc[c] >= 0.0) ? gauss_coeff64(radii[c], sigma) : 0.0;
+    }
     if (threadIdx.x == 0) {
         double m = radii[0];
         for (int c = 1; c < C; ++c) m = radii[c] > m ? radii[c] : m;
@@ -235,8 +257,9 @@ __global__ void chan_aux64_kernel(const double *radii, int C, double *rmax, doub
     }
 }
 
-hipError_t launch_chan_aux64(const double *radii, int32_t C, double *rmax, double *Rc, hipStream_t s) {
-    hipLaunchKernelGGL(chan_aux64_kernel, dim3(1), dim3(256), 0, s, radii, C, rmax, Rc);
+hipError_t launch_chan_aux64(const double *radii, int32_t C, int32_t density, double sigma, double *rmax, double *Tc, double *kc,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(chan_aux64_kernel, dim3(1), dim3(256), 0, s, radii, C, density, sigma, rmax, Tc, kc);
     return hipGetLastError();
 }
 
@@ -338,8 +361,8 @@ __device__ __forceinline__ bool prep_atom(const PrepArgs &A, int64_t a, const do
     R.px = p[0];
     R.py = p[1];
     R.pz = p[2];
-    if (f64) { // the float64 kernel divides by the radius itself (T slot); non-positive radii never contribute
-        R.T = (r64 > 0.0 && r64 < INFINITY) ? r64 : -1.0;
+    if (f64) { // float64 grids: threshold on d2 in the T slot, the float64 gaussian coefficient in the last two pad words
+        R.T = d2_threshold64(r64);
         R.k = 0.0f;
     } else {
         R.T = d2_threshold(r32);
@@ -347,6 +370,10 @@ __device__ __forceinline__ bool prep_atom(const PrepArgs &A, int64_t a, const do
     }
     R.type = type;
     R.pad[0] = R.pad[1] = R.pad[2] = 0;
+    if (f64 && A.density == MVX_GAUSSIAN && R.T >= 0.0) {
+        const double c64 = gauss_coeff64(r64, A.sigma64);
+        __builtin_memcpy(&R.pad[1], &c64, 8); // (byte 56 of the record: 8-byte aligned)
+    }
     keep = keep && (R.T >= 0.0);
 
     rng[0] = rng[1] = rng[2] = EMPTY_RANGE;
@@ -717,10 +744,14 @@ size_t dense_lds_bytes(int32_t ct, int32_t NW) {
     return (size_t)8 * lcap + 16 + (tile > cand ? tile : cand);
 }
 
+constexpr int CR64 = 8; // float64 write-out: channels per transposition round
+__host__ __device__ __forceinline__ int row_stride_doubles(int NW) { return SUBZ * NW + 8; }
 // float64 kernel: rows of 16 + 2*ct words, 64 per round (p.dcap = 64), no out tile
 size_t dense64_lds_bytes(int32_t ct, int32_t NW) {
     const int lcap = 64 * (NW < 4 ? NW : 4);
-    return (size_t)8 * lcap + 16 + (size_t)64 * (16 + 2 * ct) * 4;
+    const size_t rows = (size_t)64 * (16 + 2 * ct) * 4;
+    const size_t tile = (size_t)(ct < CR64 ? ct : CR64) * RPC * row_stride_doubles(NW) * 8;
+    return (size_t)8 * lcap + 16 + (rows > tile ? rows : tile);
 }
 
 // what a lane knows about its voxel and its workgroup's slab
@@ -871,6 +902,52 @@ __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], b
     }
 }
 
+// float64 write-out: the same transposition through an LDS tile, 8 channels per round, rows of SUBZ*NW doubles read
+// back as 16-B pairs: 32 lanes per 512-B row instead of eight 64-B runs per store instruction straight from registers
+// (2.5 -> TB/s on cfg-2). Begins with a barrier (the region may still hold candidate rows) and ends without one.
+template <int CT>
+__device__ __forceinline__ void write_slab64(const double (&acc)[CT], double *tile, int tid, int lane, int wave, int NW, int b,
+                                             int cbase, int x0, int y0, int z0, double *out, const VoxParams &P) {
+    constexpr int CR = CT < CR64 ? CT : CR64;
+    constexpr int NROUND = (CT + CR - 1) / CR;
+    const int D = P.D;
+    const int RS = row_stride_doubles(NW);
+    const size_t D2 = (size_t)D * D, D3 = D2 * D;
+    const int F2 = (SUBZ / 2) * NW;   // 16-B slots per row
+    const int nthr = NW * 64;
+    const int rows_per_pass = nthr / F2; // 16 for any NW
+    const int q = tid % F2, rfirst = tid / F2;
+    const int zq = z0 + 2 * q;
+    const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1), lx = lane >> (SUBZ_SH + SUBY_SH);
+    const int col = SUBZ * wave + lz;
+    const int rxy = lx * SUBY + ly;
+    const bool vec = P.vec_store != 0; // D even and a 16-B aligned grid
+#pragma unroll
+    for (int rd = 0; rd < NROUND; ++rd) {
+        __syncthreads(); // candidate rows (round 0) / previous tile (later rounds) fully consumed
+#pragma unroll
+        for (int c = 0; c < CR; ++c)
+            if (rd * CR + c < CT) tile[(c * RPC + rxy) * RS + col] = acc[rd * CR + c];
+        __syncthreads();
+        for (int row = rfirst; row < CR * RPC; row += rows_per_pass) {
+            const int c = row / RPC, r = row - c * RPC;
+            const int sxx = (r >> SUBY_SH) & (SUBX - 1), syy = r & (SUBY - 1);
+            const int ch = cbase + rd * CR + c;
+            if (rd * CR + c < CT && ch < P.C && x0 + sxx < D && y0 + syy < D && zq < D) {
+                const double2 v = *reinterpret_cast<const double2 *>(tile + row * RS + 2 * q);
+                double *dst = out + ((size_t)b * P.C + ch) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
+                if (vec) {
+                    typedef double d2v __attribute__((ext_vector_type(2)));
+                    __builtin_nontemporal_store((d2v){v.x, v.y}, reinterpret_cast<d2v *>(dst));
+                } else {
+                    dst[0] = v.x;
+                    if (zq + 1 < D) dst[1] = v.y;
+                }
+            }
+        }
+    }
+}
+
 // slab id t = zc + nzc * (sy + nsy * sx)
 __device__ __forceinline__ void decode_slab(unsigned t, const VoxParams &P, int &sx, int &sy, int &zc) {
     const unsigned ty = (P.nzc == 1) ? t : __umulhi(t, P.nzc_inv); // t / nzc
@@ -895,15 +972,16 @@ __device__ __forceinline__ LaneCtx make_lane_ctx(int lane, int wave, int x0, int
 }
 
 // float64 grids (precision = 64): the reference then keeps distances, ratios, densities and sums in float64
-// (numpy/voxelizer.py:33-34, 544-560), so the float32 shortcuts (threshold on d2, exp2 of a product) do not apply:
-// sqrt, divide and exp are evaluated per pair exactly as written there. The record's T slot carries the radius.
+// (numpy/voxelizer.py:33-34, 544-560). Membership sqrt_f64(d2) / r <= 1 is decided exactly by d2 <= T (d2_threshold64,
+// T in the record's T slot; per channel for channel-wise radii), so misses cost no sqrt / division; the gaussian value
+// is exp(c * d2) (gauss_coeff64, c in the record's last two words), evaluated only when some lane of the wave hits.
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
 __device__ __forceinline__ void accumulate_row64(double (&acc)[CT], const unsigned *r, const LaneCtx &L, int C,
-                                                 const double *__restrict__ Rc, double sigma) {
+                                                 const double *__restrict__ Tc, const double *__restrict__ kc) {
     const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
-    const double2 PzR = *reinterpret_cast<const double2 *>(r + 4); // pz, radius
-    const double dx = Pxy.x - L.gx, dy = Pxy.y - L.gy, dz = PzR.x - L.gz;
-    const double d = sqrt((dx * dx + dy * dy) + dz * dz); // cdist
+    const double2 PzT = *reinterpret_cast<const double2 *>(r + 4); // pz, T
+    const double dx = Pxy.x - L.gx, dy = Pxy.y - L.gy, dz = PzT.x - L.gz;
+    const double d2 = (dx * dx + dy * dy) + dz * dz; // cdist order, no fma
     bool in_range = true;
     if (LANE_RANGE) {
         const uint4 q = *reinterpret_cast<const uint4 *>(r + 8);
@@ -912,21 +990,19 @@ __device__ __forceinline__ void accumulate_row64(double (&acc)[CT], const unsign
                    (L.iy <= (int)(q.w >> 16)) && (L.iz >= (int)(zr & 0xffff)) && (L.iz <= (int)(zr >> 16));
     }
     const double *f = reinterpret_cast<const double *>(r + 16);
-    auto density = [&](double radius) -> double { // numpy/voxelizer.py:548-560
-        const double dr = d / radius;
-        if (!(dr <= 1.0) || !in_range) return 0.0;
-        if (!GAUSS) return 1.0;
-        const double t = dr / sigma;
-        return exp(-0.5 * (t * t));
-    };
     if constexpr (CHANWISE) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const int ch = (L.cbase + c < C) ? L.cbase + c : C - 1;
-            acc[c] = fma(density(Rc[ch]), f[c], acc[c]);
+            const bool hit = in_range && d2 <= Tc[ch];
+            double val = 0.0;
+            if (hit) val = GAUSS ? exp(kc[ch] * d2) : 1.0;
+            acc[c] = fma(val, f[c], acc[c]);
         }
     } else {
-        const double val = density(PzR.y);
+        const bool hit = in_range && d2 <= PzT.y;
+        double val = 0.0;
+        if (hit) val = GAUSS ? exp(*reinterpret_cast<const double *>(r + 14) * d2) : 1.0;
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = fma(val, f[c], acc[c]);
     }
@@ -970,18 +1046,14 @@ struct OpsF64 {
         for (int c = 0; c < CT; ++c) acc[c] = 0.0;
     }
     static __device__ __forceinline__ void accumulate(Acc &acc, const unsigned *r, const LaneCtx &L, const VoxParams &P,
-                                                      const double *__restrict__ Rc, const float *__restrict__) {
-        accumulate_row64<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, r, L, P.C, Rc, P.sigma);
+                                                      const double *__restrict__ Tc, const float *__restrict__ kc) {
+        // (float64 handles keep float64 per-channel coefficients behind the `kc` pointer)
+        accumulate_row64<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, r, L, P.C, Tc, reinterpret_cast<const double *>(kc));
     }
-    static __device__ __forceinline__ void write(const Acc &acc, bool, unsigned *, int, int, int, int, int b,
-                                                 const LaneCtx &L, int, int, int, void *out, const VoxParams &P) {
-        const int D = P.D;
-        if (L.ix >= D || L.iy >= D || L.iz >= D) return;
-        const size_t D3 = (size_t)D * D * D;
-        double *dst = static_cast<double *>(out) + ((size_t)b * P.C + L.cbase) * D3 + ((size_t)L.ix * D + L.iy) * D + L.iz;
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-            if (L.cbase + c < P.C) dst[(size_t)c * D3] = acc[c];
+    static __device__ __forceinline__ void write(const Acc &acc, bool, unsigned *un, int tid, int lane, int wave, int NW, int b,
+                                                 const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
+        write_slab64<CT>(acc, reinterpret_cast<double *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
+                         static_cast<double *>(out), P);
     }
 };
 

@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, ".")
 import molvoxel_amd
 
-B, N, D, C = 8, 4000, 64, 32
+B, N, D, C = (int(sys.argv[1]) if len(sys.argv) > 1 else 8), 4000, 64, 32
 rng = np.random.default_rng(0)
 W = 0.5 * (D - 1)
 coords = rng.uniform(-W / 2, W / 2, (B * N, 3))
