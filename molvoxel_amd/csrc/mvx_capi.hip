@@ -426,7 +426,8 @@ int run(mvx_handle *h, const RunArgs &r) {
     }
 
     DeviceInputs in;
-    if (direct && r.B == 1 && r.in_kind == MVX_DEVICE) { // nothing to stage: extent and transform travel by value
+    const bool by_value = (r.B == 1 && r.in_kind == MVX_DEVICE && nchunk == 1); // one molecule of device arrays
+    if (by_value) { // nothing to stage: extent and transform travel with the launches
         in.coords = r.coords;
         in.channels = r.channels;
         in.radii = r.radii;
@@ -488,6 +489,8 @@ int run(mvx_handle *h, const RunArgs &r) {
     pa.Cpad = Cpad;
     pa.offsets = in.offsets;
     pa.xforms = in.xforms;
+    std::memset(&pa.xf_one, 0, sizeof(pa.xf_one));
+    if (by_value && r.xforms) pa.xf_one = r.xforms[0];
     pa.chan_aux = d_rmax;
     pa.precision = f64 ? 64 : 32;
     pa.first = 0;
@@ -513,6 +516,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.slist = d_slist;
     va.slist_ext = d_slist_ext;
     va.offsets = in.offsets;
+    va.n_one = total;
     va.Tc = d_Tc;
     va.kc = d_kc;
     va.out = d_out;
@@ -560,13 +564,13 @@ int run(mvx_handle *h, const RunArgs &r) {
         da.T_scalar = -1.0;
         da.k_scalar = 0.0f;
         if (r.radii_type == MVX_RADII_SCALAR) scalar_radius_constants(r.radius_scalar, h->sigma32, gauss, &da.T_scalar, &da.k_scalar);
-        std::memset(&da.xf, 0, sizeof(da.xf));
         if (r.B == 1) { // one molecule: extent and transform by value, no metadata on the device
             da.pa.offsets = nullptr;
             da.pa.xforms = nullptr;
+            std::memset(&da.pa.xf_one, 0, sizeof(da.pa.xf_one));
             if (r.xforms) {
-                da.xf = r.xforms[0];
-                if (r.in_kind == MVX_HOST) resolve_host_centers(&da.xf, 1);
+                da.pa.xf_one = r.xforms[0];
+                if (r.in_kind == MVX_HOST) resolve_host_centers(&da.pa.xf_one, 1);
             }
         }
         if ((rc = timed_launch(h, s, [&] {
@@ -602,7 +606,7 @@ int run(mvx_handle *h, const RunArgs &r) {
         pa.total = r.offsets[b1];
         HIP_TRY(launch_prep(pa, pre));
         // (the first launch also zeroes the overflow counter)
-        HIP_TRY(launch_xbin(pa.xp, in.offsets, b0, b1 - b0, max_atoms, sp.nsx, sp.nsy, sp.nzc, sp.NW, d_xlist, d_slist,
+        HIP_TRY(launch_xbin(pa.xp, in.offsets, total, b0, b1 - b0, max_atoms, sp.nsx, sp.nsy, sp.nzc, sp.NW, d_xlist, d_slist,
                             d_slist_ext, k == 0 ? va.overflow : nullptr, pre));
         if (side_stream) HIP_TRY(hipEventRecord(overlap ? w.ev_pre : h->ev_pre[k], pre));
     }
@@ -627,8 +631,10 @@ int run(mvx_handle *h, const RunArgs &r) {
     } else {
         w.vox_recorded = false; // (its reads are ordered on the caller's stream only)
     }
-    HIP_TRY(hipEventRecord(in.slot->done, s));
-    in.slot->in_flight = true;
+    if (in.slot) {
+        HIP_TRY(hipEventRecord(in.slot->done, s));
+        in.slot->in_flight = true;
+    }
 
     if (r.out_kind == MVX_HOST) {
         HIP_TRY(hipMemcpyAsync(r.out, d_out, out_bytes, hipMemcpyDeviceToHost, s));

@@ -54,6 +54,7 @@ struct PrepArgs {
     int32_t Cpad;           // channel weights per atom in wbuf (zero padded)
     const int64_t *offsets; // device, B + 1
     const mvx_xform *xforms; // device, B records, or null
+    mvx_xform xf_one;       // xforms == null: the transform of the launch's only molecule (flags == 0: none)
     const void *chan_aux;   // device: [0] = max channel radius (float / double) for RAD_CHANNEL_FEATURES
     int32_t precision;      // 32 | 64: element type of radii, features, packed weights and the grid
     int64_t first;          // atoms [first, total) are processed by this launch (pipelined chunks)
@@ -94,7 +95,7 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
 // single molecule, its extent and transform by value (no metadata upload).
 struct DirectArgs {
     PrepArgs pa;   // rec / wbuf / xp / chan_aux unused; offsets / xforms: device arrays, or null for one molecule
-    mvx_xform xf;  // the transform when pa.xforms is null (flags == 0: none)
+                   // (its transform then is pa.xf_one)
     int64_t N;     // atoms of the only molecule when pa.offsets is null
     double T_scalar; // RAD_SCALAR: d2_threshold(float(radius)) and gauss_coeff, evaluated once on the host
     float k_scalar;
@@ -106,7 +107,8 @@ struct VoxArgs {
     const uint2 *xlist;    // x-slab lists (xbin_kernel)
     const uint2 *slist;    // per-slab candidate lines (xbin_kernel), SLOTS entries each
     const uint2 *slist_ext; // their extensions (entries 64..255), EXT_SLOTS entries each
-    const int64_t *offsets; // device copy of the batch offsets (x-list path only)
+    const int64_t *offsets; // device copy of the batch offsets (x-list path only), or null: one molecule of n_one atoms
+    int64_t n_one;
     const double *Tc;      // channel-wise features: per-channel d2 thresholds (float64 grids: the radii themselves)
     const float *kc;       //                        per-channel gaussian coefficients
     void *out;             // (B, C, D, D, D) float, or double for float64 grids
@@ -120,7 +122,7 @@ hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float
 hipError_t launch_chan_aux64(const double *radii, int32_t C, int32_t density, double sigma, double *rmax, double *Tc, double *kc,
                              hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
-hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int32_t b0, int32_t nb, int64_t max_atoms, int32_t nsx, int32_t nsy,
+hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, int32_t b0, int32_t nb, int64_t max_atoms, int32_t nsx, int32_t nsy,
                        int32_t nzc, int32_t NW, uint2 *xlist, uint2 *slist, uint2 *slist_ext, int *zero_counter, hipStream_t s);
 constexpr int SLAB_LINE_ENTRIES = 64;  // = SLOTS in mvx_kernels.hip
 constexpr int SLAB_EXT_ENTRIES = 192;  // = EXT_SLOTS

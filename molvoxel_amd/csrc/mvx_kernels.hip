@@ -439,6 +439,7 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
     if (a >= A.total) return;
     double p[3] = {A.coords[3 * a], A.coords[3 * a + 1], A.coords[3 * a + 2]};
     if (A.xforms) apply_xform(A.xforms[find_molecule(A.offsets, A.B, a)], p[0], p[1], p[2]); // (8 dependent loads: only when needed)
+    else if (A.xf_one.flags) apply_xform(A.xf_one, p[0], p[1], p[2]); // one molecule: its transform came with the launch
     float rmax32 = 0.0f;
     double rmax64 = 0.0;
     if (A.radii_src == RAD_CHANNEL_FEATURES) {
@@ -513,7 +514,7 @@ static_assert(SLOTS == SLAB_LINE_ENTRIES && EXT_SLOTS == SLAB_EXT_ENTRIES, "slab
 // waves, which is what 4096 blocks of a ligand batch are bound by.
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS)
-    xbin_kernel(const uint2 *__restrict__ xp, const int64_t *__restrict__ offsets, int b0, int nsx, int nsy, int nzc, int NW,
+    xbin_kernel(const uint2 *__restrict__ xp, const int64_t *__restrict__ offsets, int64_t n_one, int b0, int nsx, int nsy, int nzc, int NW,
                 uint2 *__restrict__ xlist, uint2 *__restrict__ slist, uint2 *__restrict__ slist_ext, int *zero_counter) {
     constexpr int XLN = THREADS == 64 ? 256 : XL_LDS; // one-wave blocks serve molecules of <= 256 atoms
     __shared__ uint2 xs[XLN];
@@ -523,7 +524,7 @@ __global__ void __launch_bounds__(THREADS)
     __shared__ uint2 line[NWV][4 * SLOTS]; // the four slab lines each wave is building
     const int b = b0 + blockIdx.x / nsx, sx = blockIdx.x % nsx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t a0 = offsets[b], a1 = offsets[b + 1];
+    const int64_t a0 = offsets ? offsets[b] : 0, a1 = offsets ? offsets[b + 1] : n_one; // (null: one molecule of n_one atoms)
     const int x0 = SUBX * sx;
     if (zero_counter && blockIdx.x == 0 && tid == 0) *zero_counter = 0; // overflow list of the voxelize launches
     if (tid == 0) any_overflow = 0;
@@ -655,14 +656,14 @@ __global__ void __launch_bounds__(THREADS)
     }
 }
 
-hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int32_t b0, int32_t nb, int64_t max_atoms, int32_t nsx, int32_t nsy,
+hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, int32_t b0, int32_t nb, int64_t max_atoms, int32_t nsx, int32_t nsy,
                        int32_t nzc, int32_t NW, uint2 *xlist, uint2 *slist, uint2 *slist_ext, int *zero_counter, hipStream_t s) {
     if (nb <= 0) return hipSuccess;
     const int nslab = nsy * nzc;
     if (max_atoms <= 256) { // small molecules (one round of pass A for a single wave): one-wave blocks
         int parts = 1;
         while (parts * 4 < nslab && parts < 4 && (long long)nb * nsx * parts < 8192) parts *= 2;
-        hipLaunchKernelGGL(xbin_kernel<64>, dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(64), 0, s, xp, offsets, b0, nsx, nsy,
+        hipLaunchKernelGGL(xbin_kernel<64>, dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(64), 0, s, xp, offsets, n_one, b0, nsx, nsy,
                            nzc, NW, xlist, slist, slist_ext, zero_counter);
         return hipGetLastError();
     }
@@ -670,7 +671,7 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int32_t b0, int3
     // several blocks per (molecule, x-slab), each repeating the cheap pass A, until ~2048 blocks are in flight
     int parts = 1;
     while (parts * 16 < nslab && (long long)nb * nsx * parts < 2048) parts *= 2;
-    hipLaunchKernelGGL(xbin_kernel<256>, dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(256), 0, s, xp, offsets, b0, nsx, nsy,
+    hipLaunchKernelGGL(xbin_kernel<256>, dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(256), 0, s, xp, offsets, n_one, b0, nsx, nsy,
                        nzc, NW, xlist, slist, slist_ext, zero_counter);
     return hipGetLastError();
 }
@@ -1156,7 +1157,7 @@ template <typename Ops>
 __global__ void __launch_bounds__(1024)
     voxelize_dense_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ xlist,
                           const uint2 *__restrict__ slist, const uint2 *__restrict__ slist_ext,
-                          const int64_t *__restrict__ offsets, const double *__restrict__ Tc,
+                          const int64_t *__restrict__ offsets, int64_t n_one, const double *__restrict__ Tc,
                           const float *__restrict__ kc, void *__restrict__ out, const int *__restrict__ overflow,
                           const VoxParams P, unsigned T, unsigned total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1209,7 +1210,7 @@ __global__ void __launch_bounds__(1024)
             }
         } else {
             // x-list path: more candidates than a line and its extension hold
-            const int64_t nmol = offsets[b + 1] - offsets[b];
+            const int64_t nmol = offsets ? offsets[b + 1] - offsets[b] : n_one;
             const uint2 *__restrict__ xl = xlist + ((size_t)a0 + 2 * (size_t)b) * P.nsx + (size_t)sx * (size_t)(nmol + XL_HEADER);
             const int nx = (int)xl[0].x + XL_HEADER;
             const unsigned *src = lane < 16 ? rec + lane : w + (Ops::WORDS * L.cbase + lane - 16);
@@ -1362,7 +1363,7 @@ __global__ void __launch_bounds__(MAXT, MVX_DIRECT_WPS)
         a0 = pa.offsets[b];
         a1 = pa.offsets[b + 1];
     }
-    mvx_xform xf = A.xf;
+    mvx_xform xf = pa.xf_one;
     if (pa.xforms) xf = pa.xforms[b];
     const bool has_xf = xf.flags != 0;
 
@@ -1779,7 +1780,7 @@ static hipError_t launch_dense(const VoxArgs &a, const int *overflow, size_t lds
     auto kern = &voxelize_dense_kernel<Ops>;
     hipError_t e = raise_lds_limit(kern, lds, raised);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(p.NW * 64), lds, s, a.rec, a.w, a.xlist, a.slist, a.slist_ext, a.offsets, a.Tc,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(p.NW * 64), lds, s, a.rec, a.w, a.xlist, a.slist, a.slist_ext, a.offsets, a.n_one, a.Tc,
                        a.kc, a.out, overflow, a.p, (unsigned)(p.nzc * p.nsy * p.nsx), total);
     return hipGetLastError();
 }
