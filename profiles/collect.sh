@@ -47,6 +47,19 @@ for k, d in agg.items():
         summary = {"workload": "cfg2", "batch": batch, "steps_profiled": 60, "kernel": k[:80], "write_bytes_per_launch": wr,
                    "fetch_bytes_per_launch_corrected": rd, "hbm_bytes_per_launch": wr + rd, "tag": tag,
                    "note": "WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (MI355X_MICROARCH.md HBM section: FETCH_SIZE reads half on gfx950)"}
+        # per-dispatch durations: the last 40 launches are bench.py's timed steps (the 20 before them warm the clock up)
+        durs = []
+        for f in glob.glob(out + "/kernel_trace/**/*kernel_trace.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                if "voxelize_kernel" in row["Kernel_Name"]:
+                    durs.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+        durs = [d for _, d in sorted(durs)]
+        if durs:
+            timed = durs[-40:]
+            summary["rocprof_timed_steps_avg_kernel_ns"] = sum(timed) / len(timed)
+            summary["rocprof_warmup_avg_kernel_ns"] = sum(durs[:-40]) / max(1, len(durs[:-40]))
+            lines.append(f"voxelize_kernel per-dispatch: warm-up launches avg {summary['rocprof_warmup_avg_kernel_ns']:.0f} ns, "
+                         f"timed steps (last 40) avg {summary['rocprof_timed_steps_avg_kernel_ns']:.0f} ns, min {min(timed)} max {max(timed)}")
         for r in stats:
             if "voxelize_kernel" in r["Name"]:
                 summary["rocprof_avg_kernel_ns"] = float(r["AverageNs"])

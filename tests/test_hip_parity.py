@@ -792,3 +792,48 @@ def test_overlapped_prepass_equals_serial_calls(mv):
         one = fast.forward_features(dev[0][0][:700], None, dev[0][1][:700], dev[0][3] if radii_type != "atom-wise" else dev[0][3][:700])
         assert torch.equal(one, want[0][0])
         assert torch.equal(fast.forward_batch(dev[1][0], dev[1][2], None, dev[1][1], dev[1][3], num_channels=dev[1][4]), want[1])
+
+
+def test_per_molecule_fast_path_replayed_with_changing_arguments(mv):
+    """One voxelizer object driven like the reference harness (test/test_time_numpy.py:11-15) but with everything
+    changing between calls: atom counts on both sides of every internal limit (one round of rows, one scan segment,
+    the direct / binned switch), fresh tensors (new pointers), a device-resident centre, random transforms, radii_type
+    reassigned on the live object (base/voxelizer.py:44-47) and a density switch. Every call equals the oracle."""
+    import torch
+
+    from molvoxel_amd.voxelizer.hip.transform import do_transform, draw_forward_transform
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(2024)
+    D, C_ = 48, 10
+    W_ = 0.5 * (D - 1)
+    v = mv.create_voxelizer(0.5, D, "scalar", "gaussian", "hip", sigma=0.5)
+    grid = v.get_empty_grid(C_, batch_size=2)
+    sizes = [33, 1, 48, 49, 500, 3295, 4096, 4097, 9000, 64, 2, 8192, 8193, 700]
+    step = 0
+    for radii_type in ("scalar", "atom-wise", "channel-wise", "scalar"):
+        v.radii_type = radii_type
+        for density in ("gaussian", "binary"):
+            v.density_type = density  # (back to gaussian resets sigma to 0.5: quirk Q12)
+            for n in sizes[step % 3::3]:
+                step += 1
+                xyz = rng.uniform(-W_ / 2 - 1, W_ / 2 + 1, (n, 3)) + 5.0
+                center = np.full(3, 5.0) + rng.uniform(-0.3, 0.3, 3)
+                feats = rng.random((n, C_)).astype(np.float32)
+                radii = {"scalar": 1.0 + 0.1 * (step % 4), "atom-wise": rng.uniform(0.8, 1.8, n).astype(np.float32),
+                         "channel-wise": rng.uniform(0.8, 1.8, C_).astype(np.float32)}[radii_type]
+                d_xyz, d_cen, d_f = v.asarray(xyz, "coords"), v.asarray(center, "center"), v.asarray(feats, "features")
+                d_r = radii if np.isscalar(radii) else v.asarray(radii, "radii")
+                tr, rot = (0.5, True) if step % 2 else (0.0, False)
+                np.random.seed(step)
+                out = v.forward(d_xyz, d_cen, d_f, d_r, tr, rot, out_grid=grid[step % 2])
+                np.random.seed(step)
+                translation, quaternion = draw_forward_transform(tr, rot)
+                moved = do_transform(xyz - center, None, translation, quaternion)
+                ref = c_oracle.voxelize(moved, feats, radii, dimension=D, radii_type=radii_type, density=density, sigma=0.5)
+                got = out.cpu().numpy()
+                if density == "binary":
+                    assert np.array_equal(got != 0, ref != 0), (radii_type, density, n)
+                    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(ref.max())), (radii_type, density, n)
+                else:
+                    assert_gaussian(got, ref)
