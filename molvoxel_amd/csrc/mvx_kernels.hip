@@ -1101,6 +1101,56 @@ __device__ __forceinline__ void line_round(typename Ops::Acc &acc, const uint2 E
     VK_STAMP(8 + wave); // every wave's own walk end
 }
 
+// The same round for voxelize_kernel, with the line read through the SCALAR memory path: the header and the atom
+// indices of the (at most eight) slots this wave stages are wave-uniform, so they are s_load'ed (scalar cache -> L2)
+// instead of travelling, 512 B per wave, through the vector memory pipeline - where a load queues behind the 64 KB of
+// stores every resident workgroup pushes through the same pipeline (the line load took 3 000 cycles at the median,
+// profiles/r02_phase_timelines.txt). The z sub-tile filter reads the admitted z range from the staged records instead
+// of the line's packed copy (same bits: both come from prep_atom's range, in SUBZ-voxel units).
+template <typename Ops>
+__device__ __forceinline__ void line_round_scalar(typename Ops::Acc &acc, const uint2 *__restrict__ line, int n_line, int RW,
+                                                  unsigned *un, const unsigned *__restrict__ rec, const unsigned *__restrict__ w,
+                                                  int64_t a0, int lane, int wave, int NW, const LaneCtx &L, const VoxParams &P,
+                                                  const double *__restrict__ Tc, const float *__restrict__ kc) {
+    constexpr int SW = Ops::SW;
+    const unsigned *src = lane < 16 ? rec + lane : w + (Ops::WORDS * L.cbase + lane - 16);
+    const size_t stride = lane < 16 ? (size_t)16 : (size_t)(Ops::WORDS * P.w_stride);
+    const bool stager = lane < 16 + Ops::WW;
+    int ai[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { // eight independent scalar loads
+        const int sl = wave + u * NW;
+        ai[u] = (sl >= 1 && sl <= n_line) ? (int)line[sl].x : 0;
+    }
+    unsigned v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int sl = wave + u * NW;
+        v[u] = 0u;
+        if (sl >= 1 && sl <= n_line && stager) v[u] = src[(size_t)(a0 + ai[u]) * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int sl = wave + u * NW;
+        if (sl >= 1 && sl <= n_line && stager) un[sl * SW + lane] = v[u];
+    }
+    VK_STAMP(2);
+    __syncthreads();
+    VK_STAMP(3);
+    bool ok = false;
+    if (lane >= 1 && lane <= n_line) {
+        const unsigned zr = un[lane * SW + 12];
+        ok = ((int)((zr & 0xffff) >> SUBZ_SH) <= L.zt_w) && ((int)((zr >> 16) >> SUBZ_SH) >= L.zt_w);
+    }
+    unsigned long long mask = __ballot(ok);
+    while (mask) {
+        const int sl = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        Ops::accumulate(acc, un + sl * SW, L, P, Tc, kc);
+    }
+    VK_STAMP(8 + wave); // every wave's own walk end
+}
+
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     voxelize_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist, const double *__restrict__ Tc,
@@ -1122,7 +1172,12 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     }
     b += P.b0;
     // the slab's candidate line: {count, first atom}, then {atom index, packed ranges} per candidate
+#ifdef MVX_VECTOR_LINE
     const uint2 E = slist[((size_t)b * (size_t)gridDim.x + t) * SLOTS + lane];
+#else
+    const uint2 *__restrict__ line = slist + ((size_t)b * (size_t)gridDim.x + t) * SLOTS; // (uniform: scalar loads)
+    const uint2 hdr = line[0];
+#endif
     int sx, sy, zc;
     decode_slab(t, P, sx, sy, zc);
     const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
@@ -1132,8 +1187,13 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     Ops::zero(acc);
 
     VK_STAMP(0);
+#ifdef MVX_VECTOR_LINE
     const unsigned n_hdr = (unsigned)__builtin_amdgcn_readlane((int)E.x, 0);
     const int64_t a0 = (int64_t)(unsigned)__builtin_amdgcn_readlane((int)E.y, 0);
+#else
+    const unsigned n_hdr = __builtin_amdgcn_readfirstlane(hdr.x);
+    const int64_t a0 = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane(hdr.y);
+#endif
     VK_STAMP(1); // the line has arrived
     const int RW = 8 * NW < 64 ? 8 * NW : 64; // rows this kernel can stage
     if (n_hdr >= (unsigned)RW) { // includes LINE_OVERFLOW: dense slab, left to voxelize_dense_kernel
@@ -1143,7 +1203,11 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
         }
         return;
     }
+#ifdef MVX_VECTOR_LINE
     if (n_hdr > 0) line_round<Ops>(acc, E, 0, (int)n_hdr, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
+#else
+    if (n_hdr > 0) line_round_scalar<Ops>(acc, line, (int)n_hdr, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
+#endif
     Ops::write(acc, n_hdr > 0, un, tid, lane, wave, NW, b, L, x0, y0, z0, out, P);
     VK_STAMP(6); // all stores issued
 #ifdef MVX_DIAG

@@ -2,6 +2,9 @@
 
     python3 tools/soak.py FIRST COUNT            single-molecule configurations (tests/test_hip_fuzz._draw)
     python3 tools/soak.py batches FIRST COUNT    ragged batches (tests/test_hip_fuzz.test_random_batches with other seeds)
+    python3 tools/soak.py routes FIRST COUNT     direct kernel against binned pipeline, bit for bit, on inputs that stress the
+                                                 direct kernel's float32 candidate scan: far-away centres (|c| up to 1e5),
+                                                 random rotations / translations, every radii kind and operator
 """
 import importlib.util
 import sys
@@ -14,6 +17,50 @@ spec = importlib.util.spec_from_file_location("fz", "tests/test_hip_fuzz.py")
 fz = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(fz)
 import molvoxel_amd as mv
+
+if sys.argv[1] == "routes":
+    import torch
+
+    first, count = int(sys.argv[2]), int(sys.argv[3])
+    bad, t0 = [], time.time()
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(900_000 + seed)
+        D = int(rng.choice([16, 24, 33, 48, 64]))
+        res = float(rng.choice([0.4, 0.5, 1.0]))
+        W = res * (D - 1)
+        n = int(rng.choice([1, 7, 48, 49, 64, 65, 300, 2000, 4096, 4100, 9000]))
+        scale = float(rng.choice([0.0, 10.0, 1e3, 1e4, 1e5]))
+        center = rng.uniform(-1, 1, 3) * scale
+        xyz = rng.uniform(-W / 2 - 2, W / 2 + 2, (n, 3)) + center
+        mode = str(rng.choice(["features", "types", "single"]))
+        radii_type = str(rng.choice(["scalar", "atom-wise"] + ([] if mode == "single" else ["channel-wise"])))
+        density = str(rng.choice(["gaussian", "binary"]))
+        C_ = 1 if mode == "single" else int(rng.choice([1, 3, 8, 16, 32, 40]))
+        bd = rng.choice([None, None, 4, 5, D])
+        extra = {} if bd is None else {"blockdim": int(bd)}
+        v = mv.create_voxelizer(res, D, radii_type, density, "hip", sigma=0.6, **extra)
+        chan = None if mode == "single" else (rng.random((n, C_)).astype(np.float32) if mode == "features" else rng.integers(0, C_, n))
+        if mode == "types":
+            chan[0] = C_ - 1  # max(types) + 1 == C, what channel-wise radii must match
+        radii = {"scalar": 1.3 * res / 0.5, "atom-wise": (rng.uniform(0.8, 2.0, n) * res / 0.5).astype(np.float32),
+                 "channel-wise": (rng.uniform(0.8, 2.0, C_) * res / 0.5).astype(np.float32)}[radii_type]
+        dx, dc = v.asarray(xyz, "coords"), v.asarray(center, "center")
+        dch = None if chan is None else v.asarray(chan, mode)
+        dr = radii if np.isscalar(radii) else v.asarray(radii, "radii")
+        tr, rot = float(rng.choice([0.0, 0.5, 3.0])), bool(rng.random() < 0.7)
+        outs = []
+        for route in (0, 1):
+            v.debug_option("direct", route)
+            np.random.seed(seed)
+            outs.append(v.forward(dx, dc, dch, dr, tr, rot).clone())
+        if not torch.equal(outs[0], outs[1]):
+            bad.append(seed)
+            print("MISMATCH routes seed", seed, dict(D=D, n=n, scale=scale, mode=mode, radii_type=radii_type, density=density, C=C_, bd=bd, tr=tr, rot=rot),
+                  int((outs[0] != outs[1]).sum()), flush=True)
+        if (seed - first) % 200 == 199:
+            print(f"{seed - first + 1} route cases, {len(bad)} bad, {time.time() - t0:.0f}s", flush=True)
+    print("done", count, "route cases; bad seeds:", bad)
+    sys.exit(0)
 
 if sys.argv[1] == "batches":
     first, count = int(sys.argv[2]), int(sys.argv[3])
@@ -37,8 +84,6 @@ for seed in range(first, first + count):
     if case["N"] == 0 and case["mode"] == "types":
         continue
     precision = 64 if seed % 8 == 7 else 32
-    if precision == 64 and case["C"] > 32:
-        continue
     try:
         out, moved = fz._run(mv, case, precision)
         ref = fz._reference(case, moved, precision)
