@@ -1497,6 +1497,8 @@ __global__ void __launch_bounds__(MAXT, MVX_DIRECT_WPS)
         // spot); lane l holds doubles 128k + 2l, 128k + 2l + 1 (k = 0..2) of the 384-double block
         constexpr int NBLK = SEGW / SCAN_BLOCK;
         double fd[6];
+        float fr[SCAN_BLOCK / 64]; // atom-wise radii of the block, fetched with it (a load inside the test loop would
+                                   // be waited for with vmcnt(0), i.e. together with the whole prefetch)
         auto fetch = [&](int blk) {
             const int64_t d0 = 3 * (wbeg + (int64_t)blk * SCAN_BLOCK) + 2 * lane;
 #pragma unroll
@@ -1504,6 +1506,13 @@ __global__ void __launch_bounds__(MAXT, MVX_DIRECT_WPS)
                 const int64_t d = d0 + 128 * k;
                 fd[2 * k] = pa.coords[d < dend ? d : dend - 1];
                 fd[2 * k + 1] = pa.coords[d + 1 < dend ? d + 1 : dend - 1];
+            }
+            if (pa.radii_src == RAD_ATOM) {
+#pragma unroll
+                for (int q = 0; q < SCAN_BLOCK / 64; ++q) {
+                    const int64_t a = wbeg + (int64_t)blk * SCAN_BLOCK + 64 * q + lane;
+                    fr[q] = static_cast<const float *>(pa.radii)[a < a1 ? a : a1 - 1];
+                }
             }
         };
         // one copy of the loop per kind of radius (one value for every atom / a load per atom)
@@ -1519,6 +1528,9 @@ __global__ void __launch_bounds__(MAXT, MVX_DIRECT_WPS)
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     *reinterpret_cast<float2v *>(strip + 128 * k + 2 * lane) = (float2v){(float)fd[2 * k], (float)fd[2 * k + 1]};
+                float rblk[SCAN_BLOCK / 64];
+#pragma unroll
+                for (int q = 0; q < SCAN_BLOCK / 64; ++q) rblk[q] = PER_ATOM ? fr[q] : 0.0f;
                 if (blk + 1 < NBLK && wbeg + (blk + 1) * SCAN_BLOCK < a1) fetch(blk + 1);
 #pragma unroll
                 for (int q = 0; q < SCAN_BLOCK / 64; ++q) {
@@ -1528,7 +1540,7 @@ __global__ void __launch_bounds__(MAXT, MVX_DIRECT_WPS)
                     float x = strip[3 * j], y = strip[3 * j + 1], z = strip[3 * j + 2];
                     float rwin = rscalar;
                     if constexpr (PER_ATOM) {
-                        if (pa.radii_src == RAD_ATOM) rwin = static_cast<const float *>(pa.radii)[ok ? a : a1 - 1];
+                        if (pa.radii_src == RAD_ATOM) rwin = rblk[q];
                         else {
                             const int ty = pa.types[ok ? a : a1 - 1];
                             ok = ok & (ty >= 0) & (ty < C);

@@ -75,6 +75,7 @@ class Voxelizer(BaseVoxelizer):
         self._handle = _lib.Handle()
         self._types_cache = None
         self._types_i32 = None
+        self._types_fresh = False
         self._xf = _lib.MvxXform()  # reused per call: the library copies it before the call returns
         self._xf_addr = C.addressof(self._xf)
         self._has_torch_cuda = torch is not None and torch.cuda.is_available()  # asked on every call otherwise
@@ -366,9 +367,11 @@ class Voxelizer(BaseVoxelizer):
         The converted tensor is remembered while the same unmodified tensor keeps coming (two cast kernels per call
         otherwise)."""
         hit = self._types_i32
+        self._types_fresh = False
         if hit is None or hit[0] is not t or hit[1] != t._version:
             # (the source tensor is held, not its address: a freed tensor's memory can come back with other content)
             hit = self._types_i32 = (t, t._version, t.to(device=self.device).to(torch.int16).to(torch.int32).contiguous())
+            self._types_fresh = True  # converted on the current stream a moment ago
         return hit[2]
 
     def _types_extent(self, types):
@@ -457,10 +460,18 @@ class Voxelizer(BaseVoxelizer):
             kind, C_ = "features", channels.shape[1]
         self._check_args_batch(coords, channels, kind, radii, int(C_))
         c, ch, r, in_kind, keep = self._prepare_inputs(coords, channels, kind, radii)
+        # With overlap_prepass the library's side stream reads the inputs without waiting for the caller's stream.
+        # Arrays this layer had to convert just now (dtype / layout fixes, the int32 copy of `types`) were produced
+        # ON that stream a moment ago: make them complete first (first call with a given tensor only: the copies are
+        # cached or the caller passes the right dtype)
+        fresh = self.overlap_prepass and in_kind == _lib.MVX_DEVICE and (
+            c is not coords or (kind == "features" and ch is not channels) or (r is not None and r is not radii)
+            or (kind == "types" and self._types_fresh))
         if kind == "types" and self.is_radii_type_channel_wise and r.shape[0] < C_:
             # channel-wise radii are indexed by type only; pad so the (C,) contract of the ABI holds (as forward_types)
             pad = int(C_) - r.shape[0]
             r = torch.cat([r, r.new_ones(pad)]) if _is_torch(r) else np.concatenate([r, np.ones(pad, self.fp)])
+            fresh = fresh or self.overlap_prepass
         need_xf = centers is not None or random_rotation or (random_translation and random_translation > 0.0)
         xf_ptr = None
         if need_xf:
@@ -470,6 +481,7 @@ class Voxelizer(BaseVoxelizer):
                 if in_kind == _lib.MVX_DEVICE and self._on_device(centers):  # by pointer: no copy to the host
                     dev_cen = centers.to(torch.float64).contiguous().reshape(B, 3)
                     keep.append(dev_cen)
+                    fresh = fresh or (self.overlap_prepass and dev_cen.data_ptr() != centers.data_ptr())
                 else:
                     cen = centers.detach().cpu().numpy() if _is_torch(centers) else np.asarray(centers)
                     cen = cen.reshape(B, 3)
@@ -485,6 +497,8 @@ class Voxelizer(BaseVoxelizer):
         assert tuple(out_grid.shape) == (B,) + self.grid_dimension(C_), (
             f"Output grid dimension incorrect: {tuple(out_grid.shape)} vs {(B,) + self.grid_dimension(C_)}")
         buf, out_kind, ret, how = self._resolve_out(out_grid, None)
+        if fresh:
+            torch.cuda.current_stream(self._device_index).synchronize()
         rs = float(radii) if _np_isscalar(radii) else 0.0
         off_ptr = offsets.ctypes.data
         rt = self._radii_type_code()
