@@ -498,6 +498,10 @@ int run(mvx_handle *h, const RunArgs &r) {
     pa.B = r.B;
     pa.C = r.C;
     pa.radius_scalar = r.radius_scalar;
+    pa.T_scalar = -1.0;
+    pa.k_scalar = 0.0f;
+    if (r.radii_type == MVX_RADII_SCALAR && !f64)
+        scalar_radius_constants(r.radius_scalar, h->sigma32, h->cfg.density == MVX_GAUSSIAN, &pa.T_scalar, &pa.k_scalar);
     if (r.radii_type == MVX_RADII_SCALAR) pa.radii_src = RAD_SCALAR;
     else if (r.radii_type == MVX_RADII_ATOM) pa.radii_src = RAD_ATOM;
     else pa.radii_src = chanwise ? RAD_CHANNEL_FEATURES : RAD_CHANNEL_BY_TYPE;
@@ -561,9 +565,6 @@ int run(mvx_handle *h, const RunArgs &r) {
         da.pa.xp = nullptr;
         da.pa.chan_aux = nullptr;
         da.N = total;
-        da.T_scalar = -1.0;
-        da.k_scalar = 0.0f;
-        if (r.radii_type == MVX_RADII_SCALAR) scalar_radius_constants(r.radius_scalar, h->sigma32, gauss, &da.T_scalar, &da.k_scalar);
         if (r.B == 1) { // one molecule: extent and transform by value, no metadata on the device
             da.pa.offsets = nullptr;
             da.pa.xforms = nullptr;

@@ -62,6 +62,8 @@ struct PrepArgs {
     int32_t B;
     int32_t C;
     double radius_scalar;
+    double T_scalar;        // RAD_SCALAR, float32 grids: d2_threshold(float(radius)) and gauss_coeff, evaluated once on the
+    float k_scalar;         // host (scalar_radius_constants)
     int32_t radii_src;
     int32_t density;
     float sigma32;
@@ -97,8 +99,6 @@ struct DirectArgs {
     PrepArgs pa;   // rec / wbuf / xp / chan_aux unused; offsets / xforms: device arrays, or null for one molecule
                    // (its transform then is pa.xf_one)
     int64_t N;     // atoms of the only molecule when pa.offsets is null
-    double T_scalar; // RAD_SCALAR: d2_threshold(float(radius)) and gauss_coeff, evaluated once on the host
-    float k_scalar;
 };
 
 struct VoxArgs {

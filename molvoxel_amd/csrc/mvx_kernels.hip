@@ -364,6 +364,9 @@ __device__ __forceinline__ bool prep_atom(const PrepArgs &A, int64_t a, const do
     if (f64) { // float64 grids: threshold on d2 in the T slot, the float64 gaussian coefficient in the last two pad words
         R.T = d2_threshold64(r64);
         R.k = 0.0f;
+    } else if (A.radii_src == RAD_SCALAR) { // one radius for every atom: evaluated once, on the host (same IEEE operations)
+        R.T = A.T_scalar;
+        R.k = A.k_scalar;
     } else {
         R.T = d2_threshold(r32);
         R.k = (A.density == MVX_GAUSSIAN) ? gauss_coeff(r32, A.sigma32) : 0.0f;
@@ -1683,7 +1686,7 @@ __global__ void __launch_bounds__(MAXT, MVX_DIRECT_WPS)
                     for (int i = 0; i < 3; ++i) keep = keep && (p[i] + rc > lb) && (p[i] - rc < ub); // :491-492
                 }
                 // (one python float for every atom: threshold and coefficient come with the launch)
-                const double T = pa.radii_src == RAD_SCALAR ? A.T_scalar : d2_threshold(r32);
+                const double T = pa.radii_src == RAD_SCALAR ? pa.T_scalar : d2_threshold(r32);
                 keep = keep && (T >= 0.0);
                 keep = keep && block_admits(Bx, p[0], rc) && block_admits(By, p[1], rc);
                 const double rrd = (double)r32 * 1.000001 + 1e-9; // conservative window, as prep_atom's
@@ -1692,7 +1695,7 @@ __global__ void __launch_bounds__(MAXT, MVX_DIRECT_WPS)
                 d2v *dst = reinterpret_cast<d2v *>(un + sl * SW);
                 dst[0] = (d2v){p[0], p[1]};
                 dst[1] = (d2v){p[2], T};
-                un[sl * SW + 8] = __float_as_uint(!GAUSS ? 0.0f : (pa.radii_src == RAD_SCALAR ? A.k_scalar : gauss_coeff(r32, pa.sigma32)));
+                un[sl * SW + 8] = __float_as_uint(!GAUSS ? 0.0f : (pa.radii_src == RAD_SCALAR ? pa.k_scalar : gauss_coeff(r32, pa.sigma32)));
                 un[sl * SW + 9] = (unsigned)my_type;
                 *reinterpret_cast<double *>(un + sl * SW + 10) = rc;
                 // z window radius, rounded up to float; a dropped candidate gets a negative one
