@@ -377,7 +377,9 @@ class Voxelizer(BaseVoxelizer):
     def _types_extent(self, types):
         """(min, max) of the type indices. For a device tensor this costs a kernel and a synchronisation, so the
         answer is remembered for as long as the same tensor is passed unmodified (torch bumps `_version` on every
-        in-place write) - the per-molecule loop of test/test_time_numpy.py:11-15 asks thousands of times."""
+        in-place write) - the per-molecule loop of test/test_time_numpy.py:11-15 asks thousands of times.
+        Limitation: a write that bypasses torch's version counter (`.data`, raw pointers, DLPack consumers, this
+        library's own mvx_memcpy) is not seen; such callers should pass a fresh tensor (or clone) after writing."""
         if not _is_torch(types):
             return int(types.min()), int(types.max())
         hit = self._types_cache

@@ -32,7 +32,13 @@ def test_committed_pmc_summary_matches_the_default_workload():
     assert bench.load_pmc_traffic(per_launch + 1) is None
     alg = per_launch * (4 * 32 * 64**3 + 4000 * (24 + 4 * 32 + 4))
     assert 1.0 <= d["hbm_bytes_per_launch"] / alg < 1.1  # traffic close to the algorithmic bytes: no wasted re-reads
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_line.json")))
+    for name in ("r01_bench_line.json", "r02_bench_line.json"):
+        line = json.load(open(os.path.join(ROOT, "profiles", name)))
+        _check_line(line)
+    assert line["parity_spot"] == "ok" and 0.5 < line["roofline"]["step_frac"] < line["roofline"]["frac"] < 1.0
+
+
+def _check_line(line):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line
