@@ -404,7 +404,8 @@ int run(mvx_handle *h, const RunArgs &r) {
     const bool side_stream = (nchunk > 1) || overlap;
     hipStream_t pre = s;
     if (side_stream) {
-        if (!h->side) { // lowest priority: the pre-pass should take the slots the voxelize launch leaves, not compete
+        if (!h->side) {
+            // lowest priority: the pre-pass should take the slots the voxelize launch leaves, not compete
             int lo = 0, hi = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
             HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
