@@ -208,7 +208,10 @@ int mvx_debug_read_records(mvx_handle *h, void *host_dst, int64_t n, void *strea
  * no environment variable.
  *   "chunks" = k (1..16): cut batches of >= 4k molecules into k molecule chunks whose pre-pass runs on a side stream
  *              one chunk ahead (the loop that otherwise only runs beyond 65535 (molecule, channel chunk) pairs);
- *   "max_ct" = 1..32: upper bound on the channels one workgroup accumulates (more channel chunks). */
+ *   "max_ct" = 1..32: upper bound on the channels one workgroup accumulates (more channel chunks);
+ *   "direct" = 1 / 0 / -1: always / never / automatically take the single-launch per-molecule kernel (float32 grids);
+ *   "mall_budget_kb" = k: cut batches into chunks of at most k KiB of pre-pass data (production: 288 MB, sized for
+ *              the 256 MiB Infinity Cache), so that small test batches exercise the chunk-by-chunk launch order. */
 int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value);
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@ constexpr int NSLOTS = 4;
 // per compute-unit slot: the launch is latency-bound and every launch boundary saved counts; larger launches amortise
 // the binning pre-pass, and their many empty slabs are pure store streams in voxelize_kernel - measured on 256
 // ligands: 2.04 ms direct against 0.64 ms binned) ...
+constexpr double MALL_BUDGET = 288.0e6; // bytes of pre-pass data per voxelize launch (run(): chunking for the Infinity Cache)
 constexpr long long DIRECT_MAX_WORKGROUPS = 2048;
 // ... whose largest molecule has at most this many atoms (every workgroup scans its molecule's atoms)
 constexpr int64_t DIRECT_MAX_ATOMS = 8192;
@@ -103,6 +104,7 @@ struct mvx_handle {
     std::vector<hipEvent_t> ev_pre;
     // -1: the library picks (run()); 0: always the binned three-launch pipeline; 1: always voxelize_direct_kernel
     // (where it applies: float32 grids). Set by mvx_debug_set_option("direct", v) in tests and A/B runs.
+    double mall_budget = MALL_BUDGET; // bytes; mvx_debug_set_option("mall_budget_kb", v) lowers it in tests
     int direct_mode = -1;
     int dbg = 0; // diagnostic builds (-DMVX_DIAG) only
     int store_kind = 1; // nt: measured 0.69 -> 0.54 ms on cfg-2 (output lines do not displace the re-read inputs in L2)
@@ -395,13 +397,26 @@ int run(mvx_handle *h, const RunArgs &r) {
     // ---- molecules in chunks (gridDim.y limit; optionally pre-pass on the side stream, one chunk ahead) ----------
     const int max_mol = 65535 / ncc;
     int nchunk = (r.B + max_mol - 1) / max_mol;
-    if (h->pipeline > 1 && r.B >= 4 * h->pipeline) nchunk = std::max(nchunk, h->pipeline);
+    // A chunk's pre-pass output and inputs (records, binning keys, feature rows, slab lines) are re-read ~20 times by its
+    // voxelize launch; while they fit the 256 MiB Infinity Cache the row loads are served on-die. One launch over 512
+    // cfg-2 molecules (526 MB of them) ran at 0.65 of peak against 0.76 for 256: larger batches are cut so that each
+    // chunk's set stays under MALL_BUDGET, and pre-pass and voxelize launches alternate chunk by chunk.
+    {
+        const double per_atom = 64.0 + 8.0 + 4.0 * (double)((r.C + 3) / 4 * 4) * (f64 ? 2.0 : 1.0);
+        const double ws = (double)total * per_atom + (double)r.B * (double)sp.per_molecule() * 512.0;
+        const int mall_chunks = (int)std::min<double>(std::ceil(ws / h->mall_budget), (double)std::max(1, r.B));
+        if (!f64 && mall_chunks > nchunk) nchunk = mall_chunks;
+    }
+    const bool forced_pipeline = h->pipeline > 1 && r.B >= 4 * h->pipeline;
+    if (forced_pipeline) nchunk = std::max(nchunk, h->pipeline);
     // Cross-call overlap (mvx_set_overlap): this call's pre-pass fills the other workspace set on the side stream,
     // under the previous call's voxelize launches. Device-resident inputs and outputs only.
-    const bool overlap = h->overlap && !direct && nchunk == 1 && r.in_kind == MVX_DEVICE && r.out_kind == MVX_DEVICE;
+    const bool overlap = h->overlap && !direct && nchunk == 1 && !forced_pipeline && r.in_kind == MVX_DEVICE && r.out_kind == MVX_DEVICE;
     if (overlap) h->cur ^= 1;
     Workspace &w = h->ws[h->cur];
-    const bool side_stream = (nchunk > 1) || overlap;
+    // (the side stream only serves the "chunks" test option and mvx_set_overlap; chunks cut for the cache, or for the
+    // gridDim.y limit, run their launches back to back on the caller's stream)
+    const bool side_stream = forced_pipeline || overlap;
     hipStream_t pre = s;
     if (side_stream) {
         if (!h->side) {
@@ -602,7 +617,7 @@ int run(mvx_handle *h, const RunArgs &r) {
         HIP_TRY(hipStreamWaitEvent(pre, h->ev_in, 0));
     }
     auto chunk_begin = [&](int k) { return (int)((int64_t)r.B * k / nchunk); };
-    for (int k = 0; k < nchunk; ++k) {
+    auto prepass = [&](int k) -> int {
         const int b0 = chunk_begin(k), b1 = chunk_begin(k + 1);
         pa.first = r.offsets[b0];
         pa.total = r.offsets[b1];
@@ -611,13 +626,18 @@ int run(mvx_handle *h, const RunArgs &r) {
         HIP_TRY(launch_xbin(pa.xp, in.offsets, total, b0, b1 - b0, max_atoms, sp.nsx, sp.nsy, sp.nzc, sp.NW, d_xlist, d_slist,
                             d_slist_ext, k == 0 ? va.overflow : nullptr, pre));
         if (side_stream) HIP_TRY(hipEventRecord(overlap ? w.ev_pre : h->ev_pre[k], pre));
-    }
+        return MVX_OK;
+    };
+    const bool interleave = !side_stream && !f64 && nchunk > 1; // chunk by chunk: pre-pass, then its voxelize launch
+    for (int k = 0; k < nchunk && !interleave; ++k)
+        if ((rc = prepass(k))) return rc;
     if (f64) { // float64 grids: one launch of the general slab loop over the whole batch
         for (int k = 0; k < nchunk && side_stream; ++k) HIP_TRY(hipStreamWaitEvent(s, overlap ? w.ev_pre : h->ev_pre[k], 0));
         if ((rc = timed_launch(h, s, [&] { return launch_voxelize64(va, ct, gauss, chanwise, lane_range, s); }))) return rc;
     } else {
         for (int k = 0; k < nchunk; ++k) {
             const int b0 = chunk_begin(k), b1 = chunk_begin(k + 1);
+            if (interleave && (rc = prepass(k))) return rc;
             if (side_stream) HIP_TRY(hipStreamWaitEvent(s, overlap ? w.ev_pre : h->ev_pre[k], 0));
             va.p.b0 = b0;
             // the bracket holds voxelize_kernel alone (what rocprofv3 reports under that name)
@@ -893,6 +913,7 @@ int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
     if (n == "chunks") h->pipeline = std::max(1, std::min(16, (int)value));
     else if (n == "max_ct") h->max_ct = std::max(1, std::min(32, (int)value));
     else if (n == "direct") h->direct_mode = value < 0 ? -1 : (value ? 1 : 0);
+    else if (n == "mall_budget_kb") h->mall_budget = value > 0 ? 1024.0 * (double)value : MALL_BUDGET;
 #ifdef MVX_DIAG
     else if (n == "dbg") h->dbg = value;
     else if (n == "vk_stamps") { // value = workgroups to make room for (0: off); read back with mvx_debug_read_diag

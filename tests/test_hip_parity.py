@@ -837,3 +837,33 @@ def test_per_molecule_fast_path_replayed_with_changing_arguments(mv):
                     assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(ref.max())), (radii_type, density, n)
                 else:
                     assert_gaussian(got, ref)
+
+
+def test_batches_cut_for_the_infinity_cache_match_one_launch(mv):
+    """Batches whose pre-pass data exceed the Infinity Cache budget run chunk by chunk (pre-pass, voxelize, pre-pass,
+    voxelize ...; production budget 288 MB = 256 cfg-2 molecules). With the budget lowered, a ragged batch with a dense
+    cluster (overflow list shared by all chunks), empty molecules and per-molecule transforms must give the same bits as
+    the single-launch run and match the oracle."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(77)
+    D = 32
+    W_ = 0.5 * (D - 1)
+    sizes = [300, 0, 1200, 45, 2200, 0, 700, 64, 1, 900, 1500, 30, 400, 0, 800, 650, 5, 1000]
+    coords = [rng.uniform(-W_ / 2 - 1, W_ / 2 + 1, (n, 3)) for n in sizes]
+    coords[4] = rng.normal(0.0, 0.5, (sizes[4], 3))
+    feats = [rng.random((n, 12)).astype(np.float32) for n in sizes]
+    centers = rng.uniform(-1, 1, (len(sizes), 3))
+    offsets = np.cumsum([0] + sizes)
+    allc = np.concatenate([c + centers[b] for b, c in enumerate(coords)])
+    outs = {}
+    for budget_kb in (0, 2000, 500, 100):  # 0 = production budget: one launch
+        v = mv.create_voxelizer(0.5, D, "scalar", "gaussian", "hip", sigma=0.6, output="numpy")
+        v.debug_option("direct", 0)
+        v.debug_option("mall_budget_kb", budget_kb)
+        outs[budget_kb] = v.forward_batch(allc, offsets, centers, np.concatenate(feats), 1.1).copy()
+    for k in (2000, 500, 100):
+        assert np.array_equal(outs[k], outs[0]), k
+    for b in (0, 2, 4, 10, 17):
+        assert_gaussian(outs[0][b], c_oracle.voxelize(coords[b], feats[b], 1.1, dimension=D, sigma=0.6))
+    assert not outs[0][1].any() and not outs[0][5].any()
