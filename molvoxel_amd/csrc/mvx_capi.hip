@@ -49,14 +49,15 @@ struct PinnedSlot {
 };
 
 constexpr int NSLOTS = 4;
-// voxelize_direct_kernel instead of the binned pipeline (run()): launches of at most this many workgroups (two
-// per compute-unit slot: the launch is latency-bound and every launch boundary saved counts; larger launches amortise
-// the binning pre-pass, and their many empty slabs are pure store streams in voxelize_kernel - measured on 256
-// ligands: 2.04 ms direct against 0.64 ms binned) ...
+// voxelize_direct_kernel instead of the binned pipeline (run()): launches of at most this many workgroups (the
+// launch is latency-bound and every launch boundary saved counts; larger launches amortise the binning pre-pass, and
+// their many empty slabs are pure store streams in voxelize_kernel). Measured per call, binned / direct
+// (tools/route_rule.py): 512 workgroups 70 / 42 us (12 000 atoms), 1 024 workgroups 30 / 27 us, 2 304 workgroups
+// 30 / 44 us, 4 096 workgroups 31 / 63 us; 256 ligands in one call (131 072 workgroups) 0.64 / 2.04 ms ...
 constexpr double MALL_BUDGET = 288.0e6; // bytes of pre-pass data per voxelize launch (run(): chunking for the Infinity Cache)
-constexpr long long DIRECT_MAX_WORKGROUPS = 2048;
-// ... whose largest molecule has at most this many atoms (every workgroup scans its molecule's atoms)
-constexpr int64_t DIRECT_MAX_ATOMS = 8192;
+constexpr long long DIRECT_MAX_WORKGROUPS = 1536;
+// ... and of at most this many atom tests (every workgroup scans its molecule's atoms: ~2 us per million)
+constexpr long long DIRECT_MAX_ATOM_TESTS = 16ll << 20;
 
 } // namespace
 
@@ -391,7 +392,10 @@ int run(mvx_handle *h, const RunArgs &r) {
     bool direct = false;
     if (!f64 && sp.NW <= 8 && (long long)r.B * ncc <= 65535) {
         if (h->direct_mode >= 0) direct = h->direct_mode == 1;
-        else direct = (long long)r.B * ncc * (long long)sp.per_molecule() <= DIRECT_MAX_WORKGROUPS && max_atoms <= DIRECT_MAX_ATOMS;
+        else {
+            const long long wgs = (long long)r.B * ncc * (long long)sp.per_molecule();
+            direct = wgs <= DIRECT_MAX_WORKGROUPS && (long long)ncc * (long long)sp.per_molecule() * total <= DIRECT_MAX_ATOM_TESTS;
+        }
     }
 
     // ---- molecules in chunks (gridDim.y limit; optionally pre-pass on the side stream, one chunk ahead) ----------
