@@ -1,5 +1,5 @@
 // Store-stream microbenchmark: what the grid write-out can reach for different piece sizes per workgroup.
-//   hipcc -O3 --offload-arch=gfx950 tools/micro/store_pattern.hip -o /tmp/store_pattern && /tmp/store_pattern
+//   hipcc -O3 --offload-arch=gfx950 tools/micro/store_pattern.hip -o tools/micro/store_pattern.bin (built here, run on the GPU box)
 // A "molecule" is C x D^3 floats (C = 32, D = 64). A workgroup writes, for each of its CT channels, `px` x-planes x
 // `py` y-rows x 256 B (one z row), i.e. pieces of py*256 contiguous bytes at 16-KB (x) and 1-MB (channel) strides -
 // exactly the voxelize kernel's pattern for py = 4, px = 2 (64 KB per workgroup in 64 pieces of 1 KB).
