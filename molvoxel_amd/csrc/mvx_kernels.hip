@@ -722,16 +722,23 @@ __device__ __forceinline__ void store_f4(float *dst, const float4 v, int kind) {
 __host__ __device__ __forceinline__ int row_stride_floats(int NW) { return SUBZ * NW + 8; }
 __host__ __device__ __forceinline__ int cand_stride_words(int ct) { return 16 + (ct < 4 ? 4 : ct); }
 
+#ifndef MVX_CR
+#define MVX_CR 4 // channels per transposition round of the float32 write-out: 512 threads read back exactly one 32-row tile
+                 // (cfg-2 x 256, same box: 16 -> 0.783-0.787 of peak, 8 -> 0.790, 4 -> 0.792-0.795: smaller store bursts interleave better)
+#endif
+#ifndef MVX_LDS_PAD
+#define MVX_LDS_PAD 0 // experiment: extra dynamic LDS per voxelize workgroup (fewer workgroups per compute unit)
+#endif
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW) {
-    const int cr = ct < 16 ? ct : 16;
+    const int cr = ct < MVX_CR ? ct : MVX_CR;
     const size_t tile = (size_t)cr * RPC * row_stride_floats(NW) * 4;
     const size_t cand = (size_t)64 * cand_stride_words(ct) * 4;
-    return tile > cand ? tile : cand;
+    return (tile > cand ? tile : cand) + MVX_LDS_PAD;
 }
 
 // dense kernel: candidate rows staged per round = what fits in the out tile's bytes, at least 64, at most LCAP
 int32_t voxelize_dcap(int32_t ct, int32_t NW) {
-    const int cr = ct < 16 ? ct : 16;
+    const int cr = ct < MVX_CR ? ct : MVX_CR;
     const int lcap = 64 * (NW < 4 ? NW : 4);
     const size_t tile = (size_t)cr * RPC * row_stride_floats(NW) * 4;
     int cap = (int)(tile / ((size_t)cand_stride_words(ct) * 4));
@@ -741,7 +748,7 @@ int32_t voxelize_dcap(int32_t ct, int32_t NW) {
 }
 
 size_t dense_lds_bytes(int32_t ct, int32_t NW) {
-    const int cr = ct < 16 ? ct : 16;
+    const int cr = ct < MVX_CR ? ct : MVX_CR;
     const int lcap = 64 * (NW < 4 ? NW : 4);
     const size_t tile = (size_t)cr * RPC * row_stride_floats(NW) * 4;
     const size_t cand = (size_t)voxelize_dcap(ct, NW) * cand_stride_words(ct) * 4;
@@ -836,7 +843,7 @@ template <int CT>
 __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], bool any, float *tile, int tid, int lane,
                                            int wave, int NW, int b, int cbase, int x0, int y0, int z0, float *out,
                                            const VoxParams &P) {
-    constexpr int CR = CT < 16 ? CT : 16; // channels per write-out round
+    constexpr int CR = CT < MVX_CR ? CT : MVX_CR; // channels per write-out round
     constexpr int NROUND = CT / CR;
     const int D = P.D;
     const int RS = row_stride_floats(NW);
