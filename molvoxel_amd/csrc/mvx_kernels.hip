@@ -726,14 +726,11 @@ __host__ __device__ __forceinline__ int cand_stride_words(int ct) { return 16 + 
 #define MVX_CR 4 // channels per transposition round of the float32 write-out: 512 threads read back exactly one 32-row tile
                  // (cfg-2 x 256, same box: 16 -> 0.783-0.787 of peak, 8 -> 0.790, 4 -> 0.792-0.795: smaller store bursts interleave better)
 #endif
-#ifndef MVX_LDS_PAD
-#define MVX_LDS_PAD 0 // experiment: extra dynamic LDS per voxelize workgroup (fewer workgroups per compute unit)
-#endif
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW) {
     const int cr = ct < MVX_CR ? ct : MVX_CR;
     const size_t tile = (size_t)cr * RPC * row_stride_floats(NW) * 4;
     const size_t cand = (size_t)64 * cand_stride_words(ct) * 4;
-    return (tile > cand ? tile : cand) + MVX_LDS_PAD;
+    return tile > cand ? tile : cand;
 }
 
 // dense kernel: candidate rows staged per round = what fits in the out tile's bytes, at least 64, at most LCAP
