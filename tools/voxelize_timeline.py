@@ -3,7 +3,7 @@
     python3 tools/voxelize_timeline.py [batch] [lib]          (cfg-2 molecules, default 256)
 Stamps per workgroup (s_memtime = shader cycles; only deltas inside a workgroup are meaningful):
   0 start | 1 line arrived | 2 rows staged by wave 0 | 3 staging barrier passed | 8+w walk end of wave w |
-  4 barrier after the walk | 5 round 0 transposed + stored | 6 all stores issued | 7 = candidates in the line
+  4 barrier after the walk | 5 write-out round 0 (4 channels) done | 6 all stores issued | 7 = candidates in the line
 """
 import ctypes as C
 import os
@@ -54,6 +54,6 @@ line("walk, fastest wave", walks.min(axis=1))
 line("walk, mean wave", walks.mean(axis=1))
 line("walk, slowest wave", walks.max(axis=1))
 line("walk + barrier        3 -> 4", kc(3, 4))
-line("round 0 transposition 4 -> 5", kc(4, 5))
-line("round 1 transposition 5 -> 6", kc(5, 6))
+line("write-out round 0     4 -> 5", kc(4, 5))
+line("write-out rounds 1.. 5 -> 6", kc(5, 6))
 line("workgroup life        0 -> 6", kc(0, 6))
