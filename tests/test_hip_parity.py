@@ -867,3 +867,37 @@ def test_batches_cut_for_the_infinity_cache_match_one_launch(mv):
     for b in (0, 2, 4, 10, 17):
         assert_gaussian(outs[0][b], c_oracle.voxelize(coords[b], feats[b], 1.1, dimension=D, sigma=0.6))
     assert not outs[0][1].any() and not outs[0][5].any()
+
+
+def test_non_finite_and_huge_coordinates_never_contribute(mv):
+    """NaN / infinite / astronomically large coordinates fail every comparison of the rule in the reference
+    (numpy/voxelizer.py:487-492), so such atoms contribute nothing; both routes must agree bit for bit with each other
+    and with the grid of the finite atoms alone (the direct kernel's float32 scan must not drop or invent anything)."""
+    import torch
+
+    rng = np.random.default_rng(31337)
+    D = 32
+    W_ = 0.5 * (D - 1)
+    n = 600
+    xyz = rng.uniform(-W_ / 2, W_ / 2, (n, 3))
+    bad = xyz.copy()
+    bad[5] = [np.nan, 0.0, 0.0]
+    bad[17] = [np.inf, 1.0, -1.0]
+    bad[40] = [-np.inf, np.nan, 2.0]
+    bad[99] = [1e300, 1e300, 1e300]
+    bad[123] = [3e38, -3e38, 0.5]
+    bad[200] = [1e20, 0.0, 0.0]
+    keep = np.ones(n, bool)
+    keep[[5, 17, 40, 99, 123, 200]] = False
+    f = rng.random((n, 8)).astype(np.float32)
+    for radii_type, radii in (("scalar", 1.2), ("atom-wise", rng.uniform(0.8, 1.6, n).astype(np.float32))):
+        v = mv.create_voxelizer(0.5, D, radii_type, "gaussian", "hip", sigma=0.6)
+        outs = []
+        for route in (0, 1):
+            v.debug_option("direct", route)
+            r = radii if np.isscalar(radii) else v.asarray(radii, "radii")
+            outs.append(v.forward_features(v.asarray(bad, "coords"), None, v.asarray(f, "features"), r).clone())
+        assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+        r_ok = radii if np.isscalar(radii) else v.asarray(radii[keep], "radii")
+        clean = v.forward_features(v.asarray(xyz[keep], "coords"), None, v.asarray(f[keep], "features"), r_ok)
+        assert torch.equal(outs[0], clean)
