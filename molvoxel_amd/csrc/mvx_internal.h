@@ -141,7 +141,7 @@ void scalar_radius_constants(double radius_scalar, float sigma32, bool gauss, do
 #ifdef MVX_DIAG
 hipError_t set_diag_buffer(void *p);
 #endif
-size_t voxelize_lds_bytes(int32_t ct, int32_t NW);
+size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t crmax);
 int32_t voxelize_dcap(int32_t ct, int32_t NW);
 
 } // namespace mvx

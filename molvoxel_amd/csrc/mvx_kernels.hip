@@ -726,8 +726,9 @@ __host__ __device__ __forceinline__ int cand_stride_words(int ct) { return 16 + 
 #define MVX_CR 4 // channels per transposition round of the float32 write-out: 512 threads read back exactly one 32-row tile
                  // (cfg-2 x 256, same box: 16 -> 0.783-0.787 of peak, 8 -> 0.790, 4 -> 0.792-0.795: smaller store bursts interleave better)
 #endif
-size_t voxelize_lds_bytes(int32_t ct, int32_t NW) {
-    const int cr = ct < MVX_CR ? ct : MVX_CR;
+constexpr int DIRECT_CR = 16; // write-out rounds of voxelize_direct_kernel
+size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t crmax) {
+    const int cr = ct < crmax ? ct : crmax;
     const size_t tile = (size_t)cr * RPC * row_stride_floats(NW) * 4;
     const size_t cand = (size_t)64 * cand_stride_words(ct) * 4;
     return tile > cand ? tile : cand;
@@ -836,11 +837,11 @@ __device__ __forceinline__ void accumulate_row(float2v (&acc)[(CT + 1) / 2], con
 
 // Write-out of one slab. `any` false: zero fill without the LDS round trip. Begins with a barrier (the union region
 // may still hold candidate rows) and ends without one.
-template <int CT>
+template <int CT, int CRMAX = MVX_CR>
 __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], bool any, float *tile, int tid, int lane,
                                            int wave, int NW, int b, int cbase, int x0, int y0, int z0, float *out,
                                            const VoxParams &P) {
-    constexpr int CR = CT < MVX_CR ? CT : MVX_CR; // channels per write-out round
+    constexpr int CR = CT < CRMAX ? CT : CRMAX; // channels per write-out round
     constexpr int NROUND = CT / CR;
     const int D = P.D;
     const int RS = row_stride_floats(NW);
@@ -1038,6 +1039,14 @@ struct OpsF32 {
                                                  int b, const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
         write_slab<CT>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
                        static_cast<float *>(out), P);
+    }
+    // per-molecule launches (voxelize_direct_kernel): 16 channels per round - two rounds, four barriers; the small
+    // rounds pay when thousands of workgroups' store bursts interleave, not when 512 workgroups store once (cfg-2
+    // single call 21.2 -> 20.4 us)
+    static __device__ __forceinline__ void write_wide(const Acc &acc, bool any, unsigned *un, int tid, int lane, int wave, int NW,
+                                                      int b, const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
+        write_slab<CT, DIRECT_CR>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
+                                  static_cast<float *>(out), P);
     }
 };
 
@@ -1368,7 +1377,7 @@ constexpr int DIRECT_HDR_BYTES = 64 + 256 + 32 * 8 + 32 * 4; // wcnt + pk + Tc +
 
 size_t direct_lds_bytes(int32_t ct, int32_t NW) {
     const size_t strips = (size_t)NW * SCAN_BLOCK * 12;
-    const size_t un = voxelize_lds_bytes(ct, NW);
+    const size_t un = voxelize_lds_bytes(ct, NW, DIRECT_CR);
     return (size_t)NW * SEGW * 2 + DIRECT_HDR_BYTES + (un > strips ? un : strips);
 }
 
@@ -1793,7 +1802,7 @@ __global__ void __launch_bounds__(MAXT, MVX_DIRECT_WPS)
         }
     }
     MVX_STAMP(5);
-    Ops::write(acc, any, un, tid, lane, wave, NW, b, L, x0, y0, z0, out, P);
+    Ops::write_wide(acc, any, un, tid, lane, wave, NW, b, L, x0, y0, z0, out, P);
     MVX_STAMP(6);
 #undef MVX_STAMP
 }
@@ -1878,7 +1887,7 @@ struct LaunchFn {
         if (nb <= 0) return hipSuccess;
         if ((long long)nb * p.ncc > 65535) return hipErrorInvalidConfiguration;
         static LdsLimit raised;
-        const size_t lds = voxelize_lds_bytes(CT, p.NW);
+        const size_t lds = voxelize_lds_bytes(CT, p.NW, MVX_CR);
         auto kern = &voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>;
         hipError_t e = raise_lds_limit(kern, lds, raised);
         if (e != hipSuccess) return e;
