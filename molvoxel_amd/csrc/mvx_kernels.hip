@@ -694,7 +694,7 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
 //     3. walk: each wave picks the candidates whose z range touches its sub-tile straight from the line it holds in
 //        registers (ballot) and processes them: broadcast LDS reads, fp64 d2 in cdist order, compare with T, exp2,
 //        software-pipelined weight reads + packed FMAs;
-//     4. write-out: accumulators -> LDS tile (CR = min(CT,16) channels per round) -> stores. Empty slabs skip the
+//     4. write-out: accumulators -> LDS tile (CR = min(CT, MVX_CR = 4) channels per round) -> stores. Empty slabs skip the
 //        LDS round trip.
 //   A slab with more candidates only appends its id to the overflow list and leaves.
 // voxelize_dense_kernel (dense clusters; usually the list is empty and the launch returns at once): a fixed grid
