@@ -917,6 +917,7 @@ int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
     if (n == "chunks") h->pipeline = std::max(1, std::min(16, (int)value));
     else if (n == "max_ct") h->max_ct = std::max(1, std::min(32, (int)value));
     else if (n == "direct") h->direct_mode = value < 0 ? -1 : (value ? 1 : 0);
+    else if (n == "nw") h->force_nw = value; // waves (8-voxel z sub-tiles) per slab, 1..16; 0 = the default plan
     else if (n == "mall_budget_kb") h->mall_budget = value > 0 ? 1024.0 * (double)value : MALL_BUDGET;
 #ifdef MVX_DIAG
     else if (n == "dbg") h->dbg = value;
@@ -927,6 +928,14 @@ int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
             HIP_TRY(hipMemset(h->diag.p, 0, (size_t)value * 128));
         }
         HIP_TRY(set_diag_buffer(value > 0 ? h->diag.p : nullptr));
+    }
+    else if (n == "xb_stamps") { // the same for xbin_kernel: value = blocks, 64 B each
+        DeviceGuard guard(h->device);
+        if (value > 0) {
+            if (int rc = ensure(h->diag, (size_t)value * 64)) return rc;
+            HIP_TRY(hipMemset(h->diag.p, 0, (size_t)value * 64));
+        }
+        HIP_TRY(set_diag_buffer_xb(value > 0 ? h->diag.p : nullptr));
     }
 #endif
     else return fail(MVX_ERR_INVALID, "unknown option: " + n);

@@ -140,6 +140,7 @@ hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float
 void scalar_radius_constants(double radius_scalar, float sigma32, bool gauss, double *T, float *k);
 #ifdef MVX_DIAG
 hipError_t set_diag_buffer(void *p);
+hipError_t set_diag_buffer_xb(void *p);
 #endif
 size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t crmax);
 int32_t voxelize_dcap(int32_t ct, int32_t NW);

@@ -47,8 +47,12 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ unsigned long long *g_diag = nullptr;
 #define VK_STAMP(i) do { if (g_diag && lane == 0 && (wave == 0 || (i) >= 8)) g_diag[16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 hipError_t set_diag_buffer(void *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_diag), &p, sizeof(p)); }
+__device__ unsigned long long *g_diag_xb = nullptr; // xbin_kernel: 8 x 8 B per block, stamps by thread 0
+#define XB_STAMP(i) do { if (g_diag_xb && threadIdx.x == 0) g_diag_xb[8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+hipError_t set_diag_buffer_xb(void *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_xb), &p, sizeof(p)); }
 #else
 #define VK_STAMP(i) do { } while (0)
+#define XB_STAMP(i) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -514,89 +518,112 @@ constexpr unsigned LINE_OVERFLOW = 0xffffffffu;
 static_assert(SLOTS == SLAB_LINE_ENTRIES && EXT_SLOTS == SLAB_EXT_ENTRIES, "slab line sizes are shared with the host side");
 
 // THREADS = 256, or 64 (one wave per block) for batches of small molecules: the same passes with a quarter of the
-// waves, which is what 4096 blocks of a ligand batch are bound by.
-template <int THREADS>
+// waves, which is what 4096 blocks of a ligand batch are bound by; or 1024 for a single large molecule, where the
+// kernel is a chain of latencies on a mostly idle chip: CH chunks of THREADS atoms are requested per round of pass A
+// (8 x 1024: the 10 000 atoms of cfg-5 are all in flight at once; with 256 threads and 4 chunks it took ten rounds of
+// one exposed memory latency each, 13 of the kernel's 20 us), and each of the 16 waves builds NQ = 1 line per pass.
+template <int THREADS, int XLN, int CH, int NQ>
 __global__ void __launch_bounds__(THREADS)
     xbin_kernel(const uint2 *__restrict__ xp, const int64_t *__restrict__ offsets, int64_t n_one, int b0, int nsx, int nsy, int nzc, int NW,
                 uint2 *__restrict__ xlist, uint2 *__restrict__ slist, uint2 *__restrict__ slist_ext, int *zero_counter) {
-    constexpr int XLN = THREADS == 64 ? 256 : XL_LDS; // one-wave blocks serve molecules of <= 256 atoms
-    __shared__ uint2 xs[XLN];
+    __shared__ uint2 xs[XLN]; // (one-wave blocks serve molecules of <= 256 atoms: XLN = 256)
     constexpr int NWV = THREADS / 64; // waves per block
-    __shared__ int wcnt[2][4 * NWV];
+    __shared__ int wcnt[2][NWV];
     __shared__ int any_overflow;
-    __shared__ uint2 line[NWV][4 * SLOTS]; // the four slab lines each wave is building
+    __shared__ uint2 line[NWV][NQ * SLOTS]; // the NQ slab lines each wave is building
     const int b = b0 + blockIdx.x / nsx, sx = blockIdx.x % nsx;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t a0 = offsets ? offsets[b] : 0, a1 = offsets ? offsets[b + 1] : n_one; // (null: one molecule of n_one atoms)
     const int x0 = SUBX * sx;
     if (zero_counter && blockIdx.x == 0 && tid == 0) *zero_counter = 0; // overflow list of the voxelize launches
     if (tid == 0) any_overflow = 0;
     uint2 *dst = xlist + ((size_t)a0 + 2 * (size_t)b) * nsx + (size_t)sx * (size_t)(a1 - a0 + XL_HEADER);
     int count = 0, phase = 0;
-    // four chunks of THREADS atoms per round; the next round's loads are issued before this round's barrier. Loads past
+    XB_STAMP(0);
+    // CH chunks of THREADS atoms per round; the next round's loads are issued before this round's barrier. Loads past
     // the molecule are clamped to its last atom and masked by value (a select between a global and a private
     // address would turn them into flat loads).
     if (a1 > a0) {
-        uint2 cur[4], nxt[4];
-        const int64_t alast = a1 - 1;
+        // A round takes nch <= CH chunks of 64 consecutive atoms per wave (the last round only as many as are left):
+        // wave w owns atoms [64*nch*w, 64*nch*(w+1)) of the round, so list order = atom order needs only one number per
+        // wave from the others (its total); the chunk offsets are the wave's own popcounts.
+        const int n = (int)(a1 - a0); // (a molecule's atoms are indexed in 32 bits)
+        const uint2 *__restrict__ xpm = xp + a0;
+        auto chunks_of = [&](const int rbase) {
+            const int left = n - rbase;
+            return left >= CH * THREADS ? CH : (left + THREADS - 1) / THREADS;
+        };
+        auto fetch = [&](uint2 (&v)[CH], const int rbase) {
+            const int nch = chunks_of(rbase), first = rbase + wave * nch * 64 + lane;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t a = a0 + u * THREADS + tid;
-            cur[u] = xp[a < a1 ? a : alast];
-            if (a >= a1) cur[u].x = EMPTY_RANGE;
-        }
-        for (int64_t base = a0; base < a1; base += 4 * THREADS, ++phase) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t a = base + 4 * THREADS + u * THREADS + tid;
-                nxt[u] = xp[a < a1 ? a : alast];
-                if (a >= a1) nxt[u].x = EMPTY_RANGE;
+            for (int u = 0; u < CH; ++u) {
+                const int i = first + u * 64; // clamped (a select between addresses would make it a flat load); round() masks
+                v[u] = xpm[i < n ? i : n - 1]; // (no branch per load: the compiler would wait for each one at its join)
             }
-            bool m[4];
-            unsigned long long mask[4];
+        };
+        auto round = [&](const uint2 (&v)[CH], const int rbase) {
+            const int nch = chunks_of(rbase), first = rbase + wave * nch * 64 + lane;
+            bool m[CH];
+            int cnt[CH], own = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                m[u] = ((int)(cur[u].x & 0xffff) <= x0 + SUBX - 1) && ((int)(cur[u].x >> 16) >= x0);
-                mask[u] = __ballot(m[u]);
-                if (lane == 0) wcnt[phase & 1][u * NWV + wave] = __popcll(mask[u]);
+            for (int u = 0; u < CH; ++u) {
+                m[u] = (u < nch) && (first + u * 64 < n) && ((int)(v[u].x & 0xffff) <= x0 + SUBX - 1) && ((int)(v[u].x >> 16) >= x0);
+                cnt[u] = __popcll(__ballot(m[u]));
+                own += cnt[u];
             }
+            if (lane == 0) wcnt[phase & 1][wave] = own;
+            if (phase == 0) XB_STAMP(6); // wave 0: loads arrived, matches counted
             __syncthreads();
-            int run = count;
+            int at = count;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int w = 0; w < NWV; ++w) {
+                const int c = wcnt[phase & 1][w];
+                at += (w < wave) ? c : 0;
+                count += c;
+            }
+            auto scatter = [&](auto lds_only) {
 #pragma unroll
-                for (int w = 0; w < NWV; ++w) {
-                    const int c = wcnt[phase & 1][u * NWV + w];
-                    if (w == wave && m[u]) {
-                        const int pos = run + __builtin_amdgcn_mbcnt_hi((unsigned)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[u], 0u));
-                        const uint2 en = make_uint2((unsigned)(base + u * THREADS + tid - a0), cur[u].y);
-                        if (pos < XLN) xs[pos] = en;
+                for (int u = 0; u < CH; ++u) {
+                    if (m[u]) {
+                        const unsigned long long mk = __builtin_amdgcn_read_exec(); // == ballot(m[u]) in here
+                        const int pos = at + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                        const uint2 en = make_uint2((unsigned)(first + u * 64), v[u].y);
+                        if (decltype(lds_only)::value || pos < XLN) xs[pos] = en;
                         else dst[XL_HEADER + pos] = en; // beyond the LDS copy: straight to the global list
                     }
-                    run += c;
+                    at += cnt[u];
                 }
-            }
-            count = run;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+            };
+            if (count <= XLN) scatter(std::true_type{}); // (block-uniform) the common case: the whole list fits the LDS copy
+            else scatter(std::false_type{});
+            ++phase;
+        };
+        // One register set and no prefetch across rounds: with the loads of two rounds in flight the compiler waits for
+        // the older ones before it issues the newer (register reuse across the loop's back edge), and guards around
+        // single loads end in a wait at every join. The launcher picks CH so that most molecules need one round.
+        uint2 v[CH];
+        for (int rbase = 0; rbase < n; rbase += CH * THREADS) {
+            fetch(v, rbase);
+            round(v, rbase);
         }
     }
     // the tail of a long x-list is read back by this block in pass B: workgroup-scope release here, workgroup-scope
     // loads there (an agent-scope fence makes every block write its XCD's L2 back: measured 6x on this kernel)
     __threadfence_block();
     __syncthreads();
+    XB_STAMP(1); // pass A done
 
     const int nslab = nsy * nzc;
     const size_t xslab = (size_t)b * nsx + sx;
     uint2 *sl_base = slist + xslab * (size_t)nslab * SLOTS;
     uint2 *ext_base = slist_ext + xslab * (size_t)nslab * EXT_SLOTS;
     const int nlds = count < XLN ? count : XLN;
-    // each wave builds four slab lines per pass over the x-list (one LDS read and one z test per round serve all four)
+    // each wave builds NQ slab lines per pass over the x-list (one LDS read per round serves all of them)
     // (blockIdx.y splits the slabs of one x-slab over gridDim.y blocks when a grid has many slabs per x-slab)
-    for (int g = 4 * wave + 4 * NWV * (int)blockIdx.y; g < nslab; g += 4 * NWV * (int)gridDim.y) {
-        int sy[4], zt_lo[4], zt_hi[4], n[4];
+    for (int g = NQ * wave + NQ * NWV * (int)blockIdx.y; g < nslab; g += NQ * NWV * (int)gridDim.y) {
+        int sy[NQ], zt_lo[NQ], zt_hi[NQ], n[NQ];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int sl = g + q;
             sy[q] = (sl < nslab) ? sl / nzc : 255; // 255: beyond the grid, matches no entry
             zt_lo[q] = (sl - (sl / nzc) * nzc) * NW;
@@ -608,7 +635,7 @@ __global__ void __launch_bounds__(THREADS)
             const unsigned pk = en.y;
             const int ylo = (int)(pk & 0xff), yhi = (int)((pk >> 8) & 0xff), zlo = (int)((pk >> 16) & 0xff), zhi = (int)(pk >> 24);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const bool mm = (ylo <= sy[q]) & (yhi >= sy[q]) & (zlo <= zt_hi[q]) & (zhi >= zt_lo[q]);
                 const unsigned long long mk = __ballot(mm);
                 const int pos = n[q] + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
@@ -621,10 +648,12 @@ __global__ void __launch_bounds__(THREADS)
         };
         // (two loops: a global load inside the common LDS loop would put a vmcnt(0) wait, i.e. a wait for the
         // previous round's stores, into every round)
+#pragma unroll 2
         for (int i0 = 0; i0 < nlds; i0 += 64) {
             const int i = i0 + lane;
             take(i < nlds ? xs[i] : make_uint2(0u, EMPTY_ENTRY));
         }
+        XB_STAMP(2); // pass B over the LDS part (last group of wave 0)
         for (int i0 = XLN; i0 < count; i0 += 64) { // beyond the LDS copy: this block's own stores, read back
             const int i = i0 + lane;
             uint2 en = make_uint2(0u, EMPTY_ENTRY);
@@ -634,8 +663,9 @@ __global__ void __launch_bounds__(THREADS)
             }
             take(en);
         }
+        XB_STAMP(3); // ... and the read-back tail
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             if (g + q >= nslab) break;
             // more candidates than the line and its extension hold: the slab takes the x-list path
             const unsigned hdr = (n[q] > LINE_CAP) ? LINE_OVERFLOW : (unsigned)n[q];
@@ -650,7 +680,12 @@ __global__ void __launch_bounds__(THREADS)
         }
     }
     // the global x-list is only read by slabs on the x-list path: publish the LDS part when one exists
+    XB_STAMP(4); // wave 0's lines stored
     __syncthreads();
+    XB_STAMP(5);
+#ifdef MVX_DIAG
+    if (g_diag_xb && tid == 0) g_diag_xb[8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 7] = (unsigned long long)count;
+#endif
     if (any_overflow) {
         if (tid == 0) dst[0] = make_uint2((unsigned)count, EMPTY_ENTRY);
         if (tid == 1) dst[1] = make_uint2((unsigned)a0, EMPTY_ENTRY);
@@ -666,16 +701,30 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
     if (max_atoms <= 256) { // small molecules (one round of pass A for a single wave): one-wave blocks
         int parts = 1;
         while (parts * 4 < nslab && parts < 4 && (long long)nb * nsx * parts < 8192) parts *= 2;
-        hipLaunchKernelGGL(xbin_kernel<64>, dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(64), 0, s, xp, offsets, n_one, b0, nsx, nsy,
-                           nzc, NW, xlist, slist, slist_ext, zero_counter);
+        hipLaunchKernelGGL((xbin_kernel<64, 256, 4, 4>), dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(64), 0, s, xp, offsets, n_one, b0, nsx,
+                           nsy, nzc, NW, xlist, slist, slist_ext, zero_counter);
         return hipGetLastError();
     }
     // one block builds 16 slab lines per pass; grids with more slabs per x-slab (D > 64) and few molecules get
     // several blocks per (molecule, x-slab), each repeating the cheap pass A, until ~2048 blocks are in flight
     int parts = 1;
     while (parts * 16 < nslab && (long long)nb * nsx * parts < 2048) parts *= 2;
-    hipLaunchKernelGGL(xbin_kernel<256>, dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(256), 0, s, xp, offsets, n_one, b0, nsx, nsy,
-                       nzc, NW, xlist, slist, slist_ext, zero_counter);
+#ifndef MVX_XBIN_NO_BIG
+    if ((long long)nb * nsx * parts <= 256 && max_atoms > 2048) { // at most a block per compute unit: latency is all there is
+        const dim3 grid((unsigned)(nb * nsx), (unsigned)parts);
+#define MVX_XBIN_BIG(CHUNKS)                                                                                                       \
+    hipLaunchKernelGGL((xbin_kernel<1024, 4 * XL_LDS, CHUNKS, 1>), grid, dim3(1024), 0, s, xp, offsets, n_one, b0, nsx, nsy, nzc, NW, \
+                       xlist, slist, slist_ext, zero_counter)
+        if (max_atoms <= 4 * 1024) MVX_XBIN_BIG(4); // all of the largest molecule's atoms in flight at once when <= 16 384
+        else if (max_atoms <= 8 * 1024) MVX_XBIN_BIG(8);
+        else if (max_atoms <= 12 * 1024) MVX_XBIN_BIG(12);
+        else MVX_XBIN_BIG(16);
+#undef MVX_XBIN_BIG
+        return hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL((xbin_kernel<256, XL_LDS, 4, 4>), dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(256), 0, s, xp, offsets, n_one, b0, nsx,
+                       nsy, nzc, NW, xlist, slist, slist_ext, zero_counter);
     return hipGetLastError();
 }
 

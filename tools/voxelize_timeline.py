@@ -1,6 +1,6 @@
 """Per-phase timeline of the batched voxelize_kernel from a -DMVX_DIAG build (tools/ab_build.sh diag "-DMVX_DIAG").
 
-    python3 tools/voxelize_timeline.py [batch] [lib]          (cfg-2 molecules, default 256)
+    python3 tools/voxelize_timeline.py [batch | cfg5] [lib]     (cfg-2 molecules, default 256; or one cfg-5 molecule)
 Stamps per workgroup (s_memtime = shader cycles; only deltas inside a workgroup are meaningful):
   0 start | 1 line arrived | 2 rows staged by wave 0 | 3 staging barrier passed | 8+w walk end of wave w |
   4 barrier after the walk | 5 write-out round 0 (4 channels) done | 6 all stores issued | 7 = candidates in the line
@@ -21,19 +21,28 @@ _l.SIGNATURES["mvx_debug_read_diag"] = (C.c_int, [_l.Handle, C.c_void_p, C.c_int
 import molvoxel_amd
 from molvoxel_amd import workloads as W
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-wl = W.cfg2(batch=B)
-vox = molvoxel_amd.create_voxelizer(0.5, 64, library="hip")
-coords = vox.asarray(np.concatenate(wl.coords), "coords")
-feats = vox.asarray(np.concatenate(wl.channels), "features")
-offsets = np.arange(B + 1, dtype=np.int64) * 4000
+CFG5 = len(sys.argv) > 1 and sys.argv[1] == "cfg5"  # one cfg-5 molecule (N = 10 000, 128^3), binned route
+B = 1 if CFG5 else (int(sys.argv[1]) if len(sys.argv) > 1 else 256)
+if CFG5:
+    wl = W.cfg5()
+    vox = molvoxel_amd.create_voxelizer(0.5, 128, "atom-wise", "gaussian", library="hip", sigma=1.0)
+    vox.debug_option("direct", 0)
+    radii = vox.asarray(wl.radii[0], "radii")
+    nwg = 4096
+else:
+    wl = W.cfg2(batch=B)
+    vox = molvoxel_amd.create_voxelizer(0.5, 64, library="hip")
+    radii = 1.0
+    nwg = B * 512
+coords = vox.asarray(np.concatenate(wl.coords[:B]), "coords")
+feats = vox.asarray(np.concatenate(wl.channels[:B]), "features")
+offsets = np.arange(B + 1, dtype=np.int64) * wl.coords[0].shape[0]
 out = vox.get_empty_grid(32, batch_size=B)
 for _ in range(25):
-    vox.forward_batch(coords, offsets, None, feats, 1.0, out_grid=out)
+    vox.forward_batch(coords, offsets, None, feats, radii, out_grid=out)
 torch.cuda.synchronize()
-nwg = B * 512
 vox.debug_option("vk_stamps", nwg)
-vox.forward_batch(coords, offsets, None, feats, 1.0, out_grid=out)
+vox.forward_batch(coords, offsets, None, feats, radii, out_grid=out)
 buf = np.zeros((nwg, 16), dtype=np.uint64)
 _l.check(vox._lib.mvx_debug_read_diag(vox._handle, buf.ctypes.data, buf.nbytes))
 vox.debug_option("vk_stamps", 0)
@@ -44,7 +53,7 @@ t = t[ok]
 kc = lambda a, b: (t[:, b] - t[:, a]) / 1000.0
 def line(name, x):
     print(f"{name:34s} p10 {np.percentile(x, 10):6.2f}  p50 {np.percentile(x, 50):6.2f}  p90 {np.percentile(x, 90):6.2f}  mean {x.mean():6.2f}")
-print(f"cfg-2 x {B}: {int(ok.sum())} non-empty workgroups of {nwg}; candidates per line p50 {np.median(n[ok]):.0f} max {n[ok].max():.0f}")
+print(f"{'cfg-5' if CFG5 else 'cfg-2'} x {B}: {int(ok.sum())} non-empty workgroups of {nwg}; candidates per line p50 {np.median(n[ok]):.0f} max {n[ok].max():.0f}")
 print("phase (kilocycles per workgroup)")
 line("line load             0 -> 1", kc(0, 1))
 line("row loads + LDS       1 -> 2", kc(1, 2))
