@@ -88,6 +88,7 @@ struct mvx_handle {
     int ev_count = 0;           // timed launches recorded since the last read
     bool profiling = false;
     int force_nw = 0;
+    int dense_grid = 0;
     int max_ct = 32;
     // Pipelined pre-pass (MVX_PIPELINE=k, k > 1): the batch is cut into k chunks of molecules; prep + binning of chunk
     // j+1 run on a side stream while the caller's stream voxelizes chunk j. Off by default: on cfg-2 (64 molecules)
@@ -545,6 +546,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.kc = d_kc;
     va.out = d_out;
     va.overflow = reinterpret_cast<int *>(w.overflow.p);
+    va.dense_grid = (unsigned)h->dense_grid;
     va.p.res = g.res;
     va.p.half = g.half;
     va.p.D = D;
@@ -917,6 +919,7 @@ int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
     if (n == "chunks") h->pipeline = std::max(1, std::min(16, (int)value));
     else if (n == "max_ct") h->max_ct = std::max(1, std::min(32, (int)value));
     else if (n == "direct") h->direct_mode = value < 0 ? -1 : (value ? 1 : 0);
+    else if (n == "dense_grid") h->dense_grid = value > 0 ? value : 0;
     else if (n == "nw") h->force_nw = value; // waves (8-voxel z sub-tiles) per slab, 1..16; 0 = the default plan
     else if (n == "mall_budget_kb") h->mall_budget = value > 0 ? 1024.0 * (double)value : MALL_BUDGET;
 #ifdef MVX_DIAG

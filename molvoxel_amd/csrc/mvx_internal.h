@@ -113,6 +113,7 @@ struct VoxArgs {
     const float *kc;       //                        per-channel gaussian coefficients
     void *out;             // (B, C, D, D, D) float, or double for float64 grids
     int *overflow;         // [0] = count (zeroed per call), [1..] ids of the slabs left to voxelize_dense_kernel
+    unsigned dense_grid;   // workgroups of the voxelize_dense_kernel launch (they loop over the list)
     VoxParams p;
 };
 

@@ -1951,7 +1951,7 @@ struct DenseFn {
     hipStream_t s;
     template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
     hipError_t operator()() const {
-        return launch_dense<OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE>>(a, a.overflow, dense_lds_bytes(CT, a.p.NW), 512u, 0u, s);
+        return launch_dense<OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE>>(a, a.overflow, dense_lds_bytes(CT, a.p.NW), a.dense_grid ? a.dense_grid : 512u, 0u, s);
     }
 };
 

@@ -42,6 +42,8 @@ else:
     C_ = wl.num_channels
 if os.environ.get("MVX_DBG"):  # diagnostic builds: run-time ablations of the direct kernel
     vox.debug_option("dbg", int(os.environ["MVX_DBG"]))
+if os.environ.get("MVX_DENSE_GRID"):
+    vox.debug_option("dense_grid", int(os.environ["MVX_DENSE_GRID"]))
 grid = vox.get_empty_grid(C_)
 for _ in range(20):
     vox.forward(coords, cen, chan, radii, tr, rot, out_grid=grid)

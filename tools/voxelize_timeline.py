@@ -1,6 +1,6 @@
 """Per-phase timeline of the batched voxelize_kernel from a -DMVX_DIAG build (tools/ab_build.sh diag "-DMVX_DIAG").
 
-    python3 tools/voxelize_timeline.py [batch | cfg5] [lib]     (cfg-2 molecules, default 256; or one cfg-5 molecule)
+    python3 tools/voxelize_timeline.py [batch | cfg5] [lib] [cfg-5 batch]     (cfg-2 molecules, default 256; or cfg-5 molecules)
 Stamps per workgroup (s_memtime = shader cycles; only deltas inside a workgroup are meaningful):
   0 start | 1 line arrived | 2 rows staged by wave 0 | 3 staging barrier passed | 8+w walk end of wave w |
   4 barrier after the walk | 5 write-out round 0 (4 channels) done | 6 all stores issued | 7 = candidates in the line
@@ -22,13 +22,13 @@ import molvoxel_amd
 from molvoxel_amd import workloads as W
 
 CFG5 = len(sys.argv) > 1 and sys.argv[1] == "cfg5"  # one cfg-5 molecule (N = 10 000, 128^3), binned route
-B = 1 if CFG5 else (int(sys.argv[1]) if len(sys.argv) > 1 else 256)
+B = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) if CFG5 else (int(sys.argv[1]) if len(sys.argv) > 1 else 256)
 if CFG5:
-    wl = W.cfg5()
+    wl = W.cfg5(batch=B)
     vox = molvoxel_amd.create_voxelizer(0.5, 128, "atom-wise", "gaussian", library="hip", sigma=1.0)
     vox.debug_option("direct", 0)
-    radii = vox.asarray(wl.radii[0], "radii")
-    nwg = 4096
+    radii = vox.asarray(np.concatenate(wl.radii), "radii")
+    nwg = 4096 * B
 else:
     wl = W.cfg2(batch=B)
     vox = molvoxel_amd.create_voxelizer(0.5, 64, library="hip")
