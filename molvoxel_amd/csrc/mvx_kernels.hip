@@ -631,37 +631,60 @@ __global__ void __launch_bounds__(THREADS)
             n[q] = 0;
         }
         uint2 *ln = line[wave];
-        auto take = [&](const uint2 en) { // 64 x-list entries -> appended, in order, to the lines of the slabs they touch
+        // 64 x-list entries -> appended, in order, to the lines of the slabs they touch. ZT: the z test (grids of one slab per
+        // row - nzc == 1 - need none: every listed atom's z range lies in the grid). EXT: the second sweep of a wave that
+        // met a line with more than SLOTS-1 candidates; it writes the entries 63.. to the slab's extension line, so that
+        // the common sweep carries no code for them.
+        auto take = [&](const uint2 en, auto zt, auto ext_pass) {
+            constexpr bool ZT = decltype(zt)::value, EXT = decltype(ext_pass)::value;
             const unsigned pk = en.y;
             const int ylo = (int)(pk & 0xff), yhi = (int)((pk >> 8) & 0xff), zlo = (int)((pk >> 16) & 0xff), zhi = (int)(pk >> 24);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const bool mm = (ylo <= sy[q]) & (yhi >= sy[q]) & (zlo <= zt_hi[q]) & (zhi >= zt_lo[q]);
-                const unsigned long long mk = __ballot(mm);
-                const int pos = n[q] + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                if (mm & (pos < SLOTS - 1)) ln[q * SLOTS + 1 + pos] = en;
-                n[q] += __popcll(mk);
-                if (n[q] > SLOTS - 1) { // (wave-uniform, rare) the tail goes straight to the slab's extension line
-                    if (mm && pos >= SLOTS - 1 && pos < LINE_CAP) ext_base[(size_t)(g + q) * EXT_SLOTS + (pos - (SLOTS - 1))] = en;
+                const bool c0 = ylo <= sy[q], c1 = yhi >= sy[q], c2 = zlo <= zt_hi[q], c3 = zhi >= zt_lo[q];
+                unsigned long long mk = __ballot(c0) & __ballot(c1);
+                bool mm = c0 & c1;
+                if (ZT) {
+                    mk &= __ballot(c2) & __ballot(c3);
+                    mm = mm & c2 & c3;
                 }
+                const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, (unsigned)n[q]));
+                if (!EXT) {
+                    if (mm & (pos < SLOTS - 1)) ln[q * SLOTS + 1 + pos] = en;
+                } else {
+                    if (mm & (pos >= SLOTS - 1) & (pos < LINE_CAP)) ext_base[(size_t)(g + q) * EXT_SLOTS + (pos - (SLOTS - 1))] = en;
+                }
+                n[q] += __popcll(mk);
             }
         };
-        // (two loops: a global load inside the common LDS loop would put a vmcnt(0) wait, i.e. a wait for the
-        // previous round's stores, into every round)
+        auto sweep = [&](auto zt, auto ext_pass) {
+            // (two loops: a global load inside the common LDS loop would put a vmcnt(0) wait, i.e. a wait for the
+            // previous round's stores, into every round)
 #pragma unroll 2
-        for (int i0 = 0; i0 < nlds; i0 += 64) {
-            const int i = i0 + lane;
-            take(i < nlds ? xs[i] : make_uint2(0u, EMPTY_ENTRY));
-        }
-        XB_STAMP(2); // pass B over the LDS part (last group of wave 0)
-        for (int i0 = XLN; i0 < count; i0 += 64) { // beyond the LDS copy: this block's own stores, read back
-            const int i = i0 + lane;
-            uint2 en = make_uint2(0u, EMPTY_ENTRY);
-            if (i < count) {
-                en.x = __hip_atomic_load(&dst[XL_HEADER + i].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                en.y = __hip_atomic_load(&dst[XL_HEADER + i].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int i0 = 0; i0 < nlds; i0 += 64) {
+                const int i = i0 + lane;
+                take(i < nlds ? xs[i] : make_uint2(0u, EMPTY_ENTRY), zt, ext_pass);
             }
-            take(en);
+            for (int i0 = XLN; i0 < count; i0 += 64) { // beyond the LDS copy: this block's own stores, read back
+                const int i = i0 + lane;
+                uint2 en = make_uint2(0u, EMPTY_ENTRY);
+                if (i < count) {
+                    en.x = __hip_atomic_load(&dst[XL_HEADER + i].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    en.y = __hip_atomic_load(&dst[XL_HEADER + i].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                take(en, zt, ext_pass);
+            }
+        };
+        if (nzc > 1) sweep(std::true_type{}, std::false_type{});
+        else sweep(std::false_type{}, std::false_type{});
+        XB_STAMP(2); // pass B (last group of wave 0)
+        bool full = false;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) full = full || n[q] > SLOTS - 1;
+        if (full) { // (wave-uniform, rare)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) n[q] = 0;
+            sweep(std::true_type{}, std::true_type{});
         }
         XB_STAMP(3); // ... and the read-back tail
 #pragma unroll
@@ -716,7 +739,9 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
     hipLaunchKernelGGL((xbin_kernel<1024, 4 * XL_LDS, CHUNKS, 1>), grid, dim3(1024), 0, s, xp, offsets, n_one, b0, nsx, nsy, nzc, NW, \
                        xlist, slist, slist_ext, zero_counter)
         if (max_atoms <= 4 * 1024) MVX_XBIN_BIG(4); // all of the largest molecule's atoms in flight at once when <= 16 384
+        else if (max_atoms <= 6 * 1024) MVX_XBIN_BIG(6);
         else if (max_atoms <= 8 * 1024) MVX_XBIN_BIG(8);
+        else if (max_atoms <= 10 * 1024) MVX_XBIN_BIG(10);
         else if (max_atoms <= 12 * 1024) MVX_XBIN_BIG(12);
         else MVX_XBIN_BIG(16);
 #undef MVX_XBIN_BIG

@@ -359,6 +359,28 @@ def test_long_x_list_beyond_lds_copy(mv):
         assert np.array_equal(v.forward(xyz, None, t, 1.0), ref)
 
 
+@pytest.mark.parametrize("n", [2049, 4096, 4097, 6144, 6145, 8192, 8193, 10000, 10241, 12288, 12289, 16385, 20000])
+def test_binning_of_one_large_molecule_at_every_chunk_configuration(mv, n):
+    """One large molecule on the binned route takes the 1024-thread binning configuration (xbin_kernel<1024, ., CH, 1>,
+    CH = 4 / 6 / 8 / 10 / 12 / 16 chunks of 1024 atoms in flight; above 16 384 atoms several rounds): atom counts either side
+    of every CH boundary, against the direct kernel bit for bit and against the oracle."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(n)
+    D = 48
+    W_ = 0.5 * (D - 1)
+    xyz = rng.uniform(-W_ / 2 - 1, W_ / 2 + 1, (n, 3))
+    f = rng.random((n, 8)).astype(np.float32)
+    r = rng.uniform(0.6, 1.2, n).astype(np.float32)
+    v = mv.create_voxelizer(0.5, D, "atom-wise", "gaussian", "hip", output="numpy", sigma=0.8)
+    v.debug_option("direct", 0)
+    binned = v.forward(xyz, None, f, r).copy()
+    v.debug_option("direct", 1)
+    assert np.array_equal(v.forward(xyz, None, f, r), binned)
+    if n in (4097, 10000, 16385):
+        assert_gaussian(binned, c_oracle.voxelize(xyz, f, r, dimension=D, sigma=0.8, radii_type="atom-wise"))
+
+
 def test_ragged_batch_with_one_large_molecule(mv):
     """Packed x-list regions: a 5000-atom molecule next to tiny ones in one launch."""
     from oracle import c_oracle
