@@ -286,9 +286,7 @@ int stage_inputs(mvx_handle *h, Workspace &w, const RunArgs &r, int64_t total, s
     const size_t ch_bytes = host_in ? align_up((size_t)total * chan_elem, 16) : 0;
     const size_t ra_bytes = host_in ? align_up(rad_count * esz, 16) : 0;
 
-    int rc = acquire_slot(h, off_bytes + xf_bytes + co_bytes + ch_bytes + ra_bytes, &in.slot);
-    if (rc) return rc;
-    char *pin = in.slot->p;
+    int rc;
     const void *meta_before = w.meta.p;
     if ((rc = ensure(w.meta, off_bytes + xf_bytes))) return rc;
     if (w.meta.p != meta_before) w.meta_valid = false;
@@ -297,6 +295,13 @@ int stage_inputs(mvx_handle *h, Workspace &w, const RunArgs &r, int64_t total, s
     const size_t meta_used = (size_t)(r.B + 1) * sizeof(int64_t);
     const bool meta_same = !r.xforms && w.meta_valid && w.meta_last.size() == meta_used &&
                            std::memcmp(w.meta_last.data(), r.offsets, meta_used) == 0;
+    // a pinned slot (and the event that releases it: a barrier packet on the stream, ~6 us of idle GPU) only when
+    // something is staged through it
+    char *pin = nullptr;
+    if (!meta_same || host_in) {
+        if ((rc = acquire_slot(h, off_bytes + xf_bytes + co_bytes + ch_bytes + ra_bytes, &in.slot))) return rc;
+        pin = in.slot->p;
+    }
     if (!meta_same) {
         std::memcpy(pin, r.offsets, meta_used);
         if (r.xforms) {
@@ -359,12 +364,17 @@ inline uint32_t umulhi_inverse(int d) { // n / d == __umulhi(n, inv) for the sla
 template <typename Launch>
 int timed_launch(mvx_handle *h, hipStream_t s, Launch &&launch) {
     const bool timed = h->profiling && h->ev_count < MVX_PROFILE_RING;
-    if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count], s));
-    HIP_TRY(launch());
+    if (timed) set_launch_events(h->ev[2 * h->ev_count], h->ev[2 * h->ev_count + 1]);
+    const hipError_t e = launch();
     if (timed) {
-        HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count + 1], s));
+        if (launch_events_pending()) { // nothing was launched (an empty job): keep the pair well defined
+            set_launch_events(nullptr, nullptr);
+            HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count], s));
+            HIP_TRY(hipEventRecord(h->ev[2 * h->ev_count + 1], s));
+        }
         ++h->ev_count;
     }
+    HIP_TRY(e);
     return MVX_OK;
 }
 

@@ -139,6 +139,9 @@ hipError_t launch_voxelize_dense(const VoxArgs &a, int32_t ct, bool gauss, bool 
 hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, bool chanwise,
                                   bool lane_range, hipStream_t s);
 void scalar_radius_constants(double radius_scalar, float sigma32, bool gauss, double *T, float *k);
+// profiled launches: the next voxelize launch on this thread carries these events on its own dispatch packet
+void set_launch_events(hipEvent_t start, hipEvent_t stop);
+bool launch_events_pending();
 #ifdef MVX_DIAG
 hipError_t set_diag_buffer(void *p);
 hipError_t set_diag_buffer_xb(void *p);

@@ -31,6 +31,7 @@
 
 #include <math.h>
 #include <type_traits>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <cstdlib>
 
@@ -733,19 +734,34 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
     int parts = 1;
     while (parts * 16 < nslab && (long long)nb * nsx * parts < 2048) parts *= 2;
 #ifndef MVX_XBIN_NO_BIG
-    if ((long long)nb * nsx * parts <= 256 && max_atoms > 2048) { // at most a block per compute unit: latency is all there is
-        const dim3 grid((unsigned)(nb * nsx), (unsigned)parts);
-#define MVX_XBIN_BIG(CHUNKS)                                                                                                       \
-    hipLaunchKernelGGL((xbin_kernel<1024, 4 * XL_LDS, CHUNKS, 1>), grid, dim3(1024), 0, s, xp, offsets, n_one, b0, nsx, nsy, nzc, NW, \
-                       xlist, slist, slist_ext, zero_counter)
-        if (max_atoms <= 4 * 1024) MVX_XBIN_BIG(4); // all of the largest molecule's atoms in flight at once when <= 16 384
-        else if (max_atoms <= 6 * 1024) MVX_XBIN_BIG(6);
-        else if (max_atoms <= 8 * 1024) MVX_XBIN_BIG(8);
-        else if (max_atoms <= 10 * 1024) MVX_XBIN_BIG(10);
-        else if (max_atoms <= 12 * 1024) MVX_XBIN_BIG(12);
-        else MVX_XBIN_BIG(16);
+    // Large molecules, few of them (at most two 1024-thread blocks per compute unit): latency is all there is. One
+    // block per (molecule, x-slab) with four lines per wave when that already gives >= 256 blocks (pass A runs once per
+    // pair), else one line per wave and nslab/16 blocks per pair (each repeats pass A on an otherwise idle unit).
+    if (max_atoms > 2048) {
+        const long long pairs = (long long)nb * nsx;
+        const int parts1 = (nslab + 15) / 16, parts4 = (nslab + 63) / 64;
+        const bool four = pairs * parts1 > 256;
+        const int bparts = four ? parts4 : parts1;
+        if (pairs * bparts <= 512) {
+            const dim3 grid((unsigned)pairs, (unsigned)bparts);
+#define MVX_XBIN_BIG(CHUNKS)                                                                                                          \
+    do {                                                                                                                              \
+        if (four)                                                                                                                     \
+            hipLaunchKernelGGL((xbin_kernel<1024, 2 * XL_LDS, CHUNKS, 4>), grid, dim3(1024), 0, s, xp, offsets, n_one, b0, nsx, nsy, nzc, \
+                               NW, xlist, slist, slist_ext, zero_counter);                                                            \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((xbin_kernel<1024, 4 * XL_LDS, CHUNKS, 1>), grid, dim3(1024), 0, s, xp, offsets, n_one, b0, nsx, nsy, nzc, \
+                               NW, xlist, slist, slist_ext, zero_counter);                                                            \
+    } while (0)
+            if (max_atoms <= 4 * 1024) MVX_XBIN_BIG(4); // all of the largest molecule's atoms in flight at once when <= 16 384
+            else if (max_atoms <= 6 * 1024) MVX_XBIN_BIG(6);
+            else if (max_atoms <= 8 * 1024) MVX_XBIN_BIG(8);
+            else if (max_atoms <= 10 * 1024) MVX_XBIN_BIG(10);
+            else if (max_atoms <= 12 * 1024) MVX_XBIN_BIG(12);
+            else MVX_XBIN_BIG(16);
 #undef MVX_XBIN_BIG
-        return hipGetLastError();
+            return hipGetLastError();
+        }
     }
 #endif
     hipLaunchKernelGGL((xbin_kernel<256, XL_LDS, 4, 4>), dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(256), 0, s, xp, offsets, n_one, b0, nsx,
@@ -1939,6 +1955,25 @@ static hipError_t raise_lds_limit(K kernel, size_t lds, LdsLimit &state) {
     return hipSuccess;
 }
 
+// Profiled launches (mvx_set_profiling): the two events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL:
+// start and end timestamps of this launch, what rocprofv3 reports) instead of two hipEventRecord calls around it - an
+// event recorded on the stream is a barrier packet of its own and idled the GPU ~6 us each time (kernel trace of the
+// bench: 5.9 us gaps before and after every voxelize launch). timed_launch() sets the pair, the next voxelize launch
+// on this thread consumes it.
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+void set_launch_events(hipEvent_t start, hipEvent_t stop) {
+    g_ev_start = start;
+    g_ev_stop = stop;
+}
+bool launch_events_pending() { return g_ev_start != nullptr; }
+template <typename K, typename... A>
+static void launch_profiled(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t s, A... args) {
+    const hipEvent_t e0 = g_ev_start, e1 = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
+    if (e0) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, e0, e1, 0u, args...);
+    else hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
+}
+
 template <typename Ops>
 static hipError_t launch_dense(const VoxArgs &a, const int *overflow, size_t lds, unsigned grid, unsigned total, hipStream_t s) {
     static LdsLimit raised;
@@ -1946,8 +1981,8 @@ static hipError_t launch_dense(const VoxArgs &a, const int *overflow, size_t lds
     auto kern = &voxelize_dense_kernel<Ops>;
     hipError_t e = raise_lds_limit(kern, lds, raised);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(p.NW * 64), lds, s, a.rec, a.w, a.xlist, a.slist, a.slist_ext, a.offsets, a.n_one, a.Tc,
-                       a.kc, a.out, overflow, a.p, (unsigned)(p.nzc * p.nsy * p.nsx), total);
+    launch_profiled(kern, dim3(grid), dim3(p.NW * 64), lds, s, a.rec, a.w, a.xlist, a.slist, a.slist_ext, a.offsets, a.n_one, a.Tc, a.kc,
+                    a.out, overflow, a.p, (unsigned)(p.nzc * p.nsy * p.nsx), total);
     return hipGetLastError();
 }
 
@@ -1965,8 +2000,8 @@ struct LaunchFn {
         auto kern = &voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>;
         hipError_t e = raise_lds_limit(kern, lds, raised);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), lds, s,
-                           a.rec, a.w, a.slist, a.Tc, a.kc, static_cast<float *>(a.out), a.overflow, a.p);
+        launch_profiled(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), lds, s, a.rec, a.w,
+                        a.slist, a.Tc, a.kc, static_cast<float *>(a.out), a.overflow, a.p);
         return hipGetLastError();
     }
 };
@@ -2015,8 +2050,7 @@ struct DirectFn {
             auto kern = &voxelize_direct_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>;
             hipError_t e = raise_lds_limit(kern, lds, raised);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(p.B * p.ncc)), dim3(p.NW * 64), lds, s, d,
-                               out, p);
+            launch_profiled(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(p.B * p.ncc)), dim3(p.NW * 64), lds, s, d, out, p);
             return hipGetLastError();
         }
     }
