@@ -89,6 +89,7 @@ struct mvx_handle {
     bool profiling = false;
     int force_nw = 0;
     int dense_grid = 0;
+    int max_ct64 = 32; // channels per workgroup on float64 grids (debug option "max_ct64": 16 = two chunks for C = 32)
     int max_ct = 32;
     // Pipelined pre-pass (MVX_PIPELINE=k, k > 1): the batch is cut into k chunks of molecules; prep + binning of chunk
     // j+1 run on a side stream while the caller's stream voxelizes chunk j. Off by default: on cfg-2 (64 molecules)
@@ -344,13 +345,13 @@ struct SlabPlan {
     size_t per_molecule() const { return (size_t)nsx * nsy * nzc; }
 };
 
-SlabPlan plan_slabs(const mvx_handle *h) {
+SlabPlan plan_slabs(const mvx_handle *h, int max_waves) {
     const int D = h->g.D;
     SlabPlan sp;
     sp.nsx = (D + SUBX - 1) / SUBX;
     sp.nsy = (D + SUBY - 1) / SUBY;
     const int nsz = (D + SUBZ - 1) / SUBZ;
-    sp.NW = nsz <= 8 ? nsz : 8;
+    sp.NW = nsz <= max_waves ? nsz : max_waves;
     if (h->force_nw > 0 && h->force_nw <= 16) sp.NW = std::min(h->force_nw, nsz); // MVX_NW experiment knob
     sp.nzc = (nsz + sp.NW - 1) / sp.NW;
     return sp;
@@ -394,9 +395,16 @@ int run(mvx_handle *h, const RunArgs &r) {
     const size_t out_bytes = (size_t)r.B * r.C * D * D * D * esz;
 
     // channels per workgroup (register accumulators per lane); more channels -> several channel chunks
-    const int ct = pick_ct(std::min(r.C, f64 ? std::min(h->max_ct, 16) : h->max_ct)); // float64 rows: <= 16 channels
+    // float64 grids: 16 channels per workgroup (two chunks for C = 32: 105 VGPRs, two 8-wave workgroups per compute
+    // unit). Gaussian grids of more than 16 channels take 32 per workgroup on 4-wave slabs instead (147 VGPRs, three
+    // workgroups per unit): distances and exp are evaluated once per slab instead of once per chunk, 3.4 -> 3.7 TB/s on
+    // cfg-2; the binary kernel has no exp to save and is faster as it was (4.1 against 3.5 TB/s). Measured and not used:
+    // 32 channels on 8-wave slabs (one workgroup per unit: 3.05 / 2.7 TB/s), 16 channels squeezed into 80 VGPRs for
+    // three 8-wave workgroups (26 dwords of scratch in the walk: 2.5 TB/s).
+    const bool wide64 = f64 && h->cfg.density == MVX_GAUSSIAN && r.C > 16 && h->max_ct64 >= 32 && h->max_ct >= 32 && h->force_nw == 0;
+    const SlabPlan sp = plan_slabs(h, wide64 ? 4 : 8);
+    const int ct = pick_ct(std::min(r.C, f64 ? (wide64 ? 32 : std::min(h->max_ct, h->max_ct64 >= 32 && sp.NW <= 8 && h->force_nw ? 32 : 16)) : h->max_ct));
     const int ncc = (r.C + ct - 1) / ct;
-    const SlabPlan sp = plan_slabs(h);
     // One launch for the whole call (voxelize_direct_kernel) when the per-workgroup atom scan is cheap next to the
     // slab's stores: per-molecule forward() calls, and batches of small molecules. Bigger jobs amortise the binning
     // pre-pass and take the three-launch pipeline.
@@ -929,6 +937,7 @@ int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
     if (n == "chunks") h->pipeline = std::max(1, std::min(16, (int)value));
     else if (n == "max_ct") h->max_ct = std::max(1, std::min(32, (int)value));
     else if (n == "direct") h->direct_mode = value < 0 ? -1 : (value ? 1 : 0);
+    else if (n == "max_ct64") h->max_ct64 = value >= 32 ? 32 : 16;
     else if (n == "dense_grid") h->dense_grid = value > 0 ? value : 0;
     else if (n == "nw") h->force_nw = value; // waves (8-voxel z sub-tiles) per slab, 1..16; 0 = the default plan
     else if (n == "mall_budget_kb") h->mall_budget = value > 0 ? 1024.0 * (double)value : MALL_BUDGET;

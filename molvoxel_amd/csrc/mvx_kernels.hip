@@ -1147,7 +1147,7 @@ struct OpsF64 {
     static constexpr int WORDS = 2;
     static constexpr int WW = 2 * CT;
     static constexpr int SW = 16 + 2 * CT;
-    static_assert(16 + WW <= 64, "a row is staged by one wave-wide load");
+    static_assert(16 + WW <= 128, "a row is staged by at most two wave-wide loads");
     static __device__ __forceinline__ void zero(Acc &acc) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = 0.0;
@@ -1177,20 +1177,26 @@ __device__ __forceinline__ void line_round(typename Ops::Acc &acc, const uint2 E
     const unsigned *src = lane < 16 ? rec + lane : w + (Ops::WORDS * L.cbase + lane - 16);
     const size_t stride = lane < 16 ? (size_t)16 : (size_t)(Ops::WORDS * P.w_stride);
     const bool stager = lane < 16 + Ops::WW;
-    unsigned v[8];
+    // rows wider than a wave (float64, 32 channels: 16 + 64 words): lanes 0.. fetch words 64.. with a second load
+    constexpr int TAIL = 16 + Ops::WW > 64 ? 16 + Ops::WW - 64 : 0;
+    const unsigned *src2 = w + (Ops::WORDS * L.cbase + lane + 48);
+    unsigned v[8], v2[TAIL ? 8 : 1];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int sl = wave + u * NW; // row slot staged by this wave (wave-uniform) <-> entry e0 + sl
         v[u] = 0u;
+        if (TAIL) v2[u] = 0u;
         if (sl < RW && e0 + sl >= 1 && e0 + sl <= n_line) {
             const int ai = __builtin_amdgcn_readlane((int)Er.x, sl & 63);
             if (stager) v[u] = src[(size_t)(a0 + ai) * stride];
+            if (TAIL && lane < TAIL) v2[u] = src2[(size_t)(a0 + ai) * (size_t)(Ops::WORDS * P.w_stride)];
         }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int sl = wave + u * NW;
         if (sl < RW && e0 + sl >= 1 && e0 + sl <= n_line && stager) un[sl * SW + lane] = v[u];
+        if (TAIL && sl < RW && e0 + sl >= 1 && e0 + sl <= n_line && lane < TAIL) un[sl * SW + 64 + lane] = v2[u];
     }
     VK_STAMP(2);
     __syncthreads();
@@ -1323,8 +1329,8 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
 
 // The general slab loop. float32: over the overflow list of the voxelize_kernel launches. float64: `overflow` is
 // null and the loop runs over all `total` (molecule, chunk, slab) ids.
-template <typename Ops>
-__global__ void __launch_bounds__(1024)
+template <typename Ops, int MAXT, int WPE>
+__global__ void __launch_bounds__(MAXT, WPE)
     voxelize_dense_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ xlist,
                           const uint2 *__restrict__ slist, const uint2 *__restrict__ slist_ext,
                           const int64_t *__restrict__ offsets, int64_t n_one, const double *__restrict__ Tc,
@@ -1386,6 +1392,7 @@ __global__ void __launch_bounds__(1024)
             const unsigned *src = lane < 16 ? rec + lane : w + (Ops::WORDS * L.cbase + lane - 16);
             const size_t stride = lane < 16 ? (size_t)16 : (size_t)(Ops::WORDS * P.w_stride);
             const bool stager = lane < 16 + Ops::WW;
+            constexpr int TAIL = 16 + Ops::WW > 64 ? 16 + Ops::WW - 64 : 0;
             for (int base = 0; base < nx; base += LCAP) {
                 __syncthreads(); // list / candidate rows of the previous round consumed
                 if (wave == 0) { // ordered compaction of LCAP entries against the slab's y/z box
@@ -1412,8 +1419,11 @@ __global__ void __launch_bounds__(1024)
                 for (int c0 = 0; c0 < nl; c0 += P.dcap) {
                     const int n = (nl - c0) < P.dcap ? (nl - c0) : P.dcap; // rows staged this round
                     if (c0 > 0) __syncthreads();
-                    for (int j = wave; j < n; j += NW)
+                    for (int j = wave; j < n; j += NW) {
                         if (stager) un[j * SW + lane] = src[(size_t)(a0 + list[c0 + j]) * stride];
+                        if (TAIL && lane < TAIL) // (rows wider than a wave: float64, 32 channels)
+                            un[j * SW + 64 + lane] = (w + (Ops::WORDS * L.cbase + lane + 48))[(size_t)(a0 + list[c0 + j]) * (size_t)(Ops::WORDS * P.w_stride)];
+                    }
                     __syncthreads();
                     for (int jb = 0; jb < n; jb += 64) {
                         const int j = jb + lane;
@@ -1974,11 +1984,12 @@ static void launch_profiled(K kern, dim3 grid, dim3 block, size_t lds, hipStream
     else hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
 }
 
-template <typename Ops>
+template <typename Ops, int MAXT = 1024, int WPE = 1>
 static hipError_t launch_dense(const VoxArgs &a, const int *overflow, size_t lds, unsigned grid, unsigned total, hipStream_t s) {
     static LdsLimit raised;
     const VoxParams &p = a.p;
-    auto kern = &voxelize_dense_kernel<Ops>;
+    if (p.NW * 64 > MAXT) return hipErrorInvalidConfiguration;
+    auto kern = &voxelize_dense_kernel<Ops, MAXT, WPE>;
     hipError_t e = raise_lds_limit(kern, lds, raised);
     if (e != hipSuccess) return e;
     launch_profiled(kern, dim3(grid), dim3(p.NW * 64), lds, s, a.rec, a.w, a.xlist, a.slist, a.slist_ext, a.offsets, a.n_one, a.Tc, a.kc,
@@ -2020,14 +2031,20 @@ struct Dense64Fn {
     hipStream_t s;
     template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
     hipError_t operator()() const {
+        const VoxParams &p = a.p;
+        const long long total = (long long)p.B * p.ncc * p.nzc * p.nsy * p.nsx;
+        if (total <= 0) return hipSuccess;
+        if (total > 0xffffffffll) return hipErrorInvalidConfiguration;
+        const unsigned grid = (unsigned)(total < 4096 ? total : 4096);
         if constexpr (CT > 16) {
-            return hipErrorInvalidValue; // float64 rows are staged 16 channels at a time
+            // 32 float64 accumulators per lane: 512-thread workgroups (the plan's slabs have at most 8 waves), so the
+            // kernel may use 256 VGPRs; one chunk instead of two halves the staging, distance and exp work per slab
+            if (p.NW > 8) return hipErrorInvalidValue;
+            return launch_dense<OpsF64<CT, GAUSS, CHANWISE, LANE_RANGE>, 512>(a, nullptr, dense64_lds_bytes(CT, p.NW), grid, (unsigned)total, s);
         } else {
-            const VoxParams &p = a.p;
-            const long long total = (long long)p.B * p.ncc * p.nzc * p.nsy * p.nsx;
-            if (total <= 0) return hipSuccess;
-            if (total > 0xffffffffll) return hipErrorInvalidConfiguration;
-            const unsigned grid = (unsigned)(total < 4096 ? total : 4096);
+#ifdef MVX_F64_WPE
+            if (p.NW <= 8) return launch_dense<OpsF64<CT, GAUSS, CHANWISE, LANE_RANGE>, 512, MVX_F64_WPE>(a, nullptr, dense64_lds_bytes(CT, p.NW), grid, (unsigned)total, s);
+#endif
             return launch_dense<OpsF64<CT, GAUSS, CHANWISE, LANE_RANGE>>(a, nullptr, dense64_lds_bytes(CT, p.NW), grid, (unsigned)total, s);
         }
     }

@@ -719,8 +719,8 @@ def test_interleaved_calls_on_two_streams_without_synchronisation(mv):
                                                 ("types", "channel-wise", 40), ("types", "atom-wise", 33),
                                                 ("features", "atom-wise", 48)])
 def test_precision64_more_than_32_channels(mv, mode, radii_type, C_):
-    """float64 rows are staged 16 channels at a time: C > 32 means three or more chunks (packed double weights,
-    Cpad = 48, channel-wise radii clamped at C - 1 in the last chunk)."""
+    """float64 workgroups take 16 channels (32 for Gaussian grids of more than 16 channels): C > 32 means several
+    chunks (packed double weights, Cpad = 48, channel-wise radii clamped at C - 1 in the last chunk)."""
     from oracle import numpy_port
 
     rng = np.random.default_rng(64 + C_)
@@ -742,6 +742,12 @@ def test_precision64_more_than_32_channels(mv, mode, radii_type, C_):
             assert_exact(out, ref)
         else:
             assert_gaussian(out, ref, P64_TOL)
+        # Gaussian grids of more than 16 channels take 32 channels per workgroup on 4-wave slabs by default; the
+        # 16-channel form (what binary grids use) is one debug option away and must agree in every voxel
+        v.debug_option("max_ct64", 16)
+        narrow = v.forward(xyz, None, chan, radii)
+        assert np.array_equal(narrow != 0, out != 0)
+        assert np.abs(narrow - out).max() <= 1e-13 * max(1.0, np.abs(out).max())
 
 
 def test_forward_batch_rejects_short_arrays(mv):
