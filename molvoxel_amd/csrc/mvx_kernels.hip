@@ -2042,9 +2042,6 @@ struct Dense64Fn {
             if (p.NW > 8) return hipErrorInvalidValue;
             return launch_dense<OpsF64<CT, GAUSS, CHANWISE, LANE_RANGE>, 512>(a, nullptr, dense64_lds_bytes(CT, p.NW), grid, (unsigned)total, s);
         } else {
-#ifdef MVX_F64_WPE
-            if (p.NW <= 8) return launch_dense<OpsF64<CT, GAUSS, CHANWISE, LANE_RANGE>, 512, MVX_F64_WPE>(a, nullptr, dense64_lds_bytes(CT, p.NW), grid, (unsigned)total, s);
-#endif
             return launch_dense<OpsF64<CT, GAUSS, CHANWISE, LANE_RANGE>>(a, nullptr, dense64_lds_bytes(CT, p.NW), grid, (unsigned)total, s);
         }
     }
