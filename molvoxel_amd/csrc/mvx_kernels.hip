@@ -289,14 +289,24 @@ __device__ __forceinline__ void block_interval(const Geom &g, double p, double r
     auto bound = [&](int m) { return ((double)((m + 1) * g.bd) * g.res - g.half) + hres; }; // numpy/voxelizer.py:55
     const double inv_pitch = g.inv_pitch; // 1 / (bd * res): the estimates below need not be exact
     auto clampi = [&](double v) { return v < 0.0 ? 0 : (v > (double)last ? last : (int)v); };
+    // count = #{m < nb-1 : cond(m)} for a predicate that is true exactly below the count: the estimate is right when
+    // cond fails at it and holds just below it - two evaluations, straight-line - and is walked to the flip otherwise
+    // (rare; the loops must not be interleaved: left to itself the compiler evaluates four bounds per trip, ~120
+    // instructions before a loop can leave, 840 of the kernel's 890 vector instructions per atom).
+    auto settle = [&](int b, auto cond) {
+        const bool up = (b < last) & cond(b), down = (b > 0) & !cond(b - 1);
+        if (up | down) {
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+            while (b < last && cond(b)) ++b;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+            while (b > 0 && !cond(b - 1)) --b;
+        }
+        return b;
+    };
     // bhi = #{m < nb-1 : p > bound(m) - r}
-    int bhi = clampi(floor((p + r + g.half - hres) * inv_pitch));
-    while (bhi < last && p > bound(bhi) - r) ++bhi;
-    while (bhi > 0 && !(p > bound(bhi - 1) - r)) --bhi;
+    const int bhi = settle(clampi(floor((p + r + g.half - hres) * inv_pitch)), [&](int m) { return p > bound(m) - r; });
     // blo = #{m < nb-1 : !(p < bound(m) + r)}
-    int blo = clampi(floor((p - r + g.half - hres) * inv_pitch));
-    while (blo < last && !(p < bound(blo) + r)) ++blo;
-    while (blo > 0 && (p < bound(blo - 1) + r)) --blo;
+    const int blo = settle(clampi(floor((p - r + g.half - hres) * inv_pitch)), [&](int m) { return !(p < bound(m) + r); });
     vlo = blo * g.bd;
     vhi = (bhi + 1) * g.bd - 1;
     if (vhi > g.D - 1) vhi = g.D - 1;
@@ -444,9 +454,11 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
             else static_cast<float *>(A.wbuf)[first * A.Cpad + i] = (float)f;
         }
     }
-    if (a >= A.total) return;
-    double p[3] = {A.coords[3 * a], A.coords[3 * a + 1], A.coords[3 * a + 2]};
-    if (A.xforms) apply_xform(A.xforms[find_molecule(A.offsets, A.B, a)], p[0], p[1], p[2]); // (8 dependent loads: only when needed)
+    // (no early return: every thread takes part in the record transposition below)
+    const bool live = a < A.total;
+    const int64_t al = live ? a : A.total - 1; // (A.total > A.first: launch_prep)
+    double p[3] = {A.coords[3 * al], A.coords[3 * al + 1], A.coords[3 * al + 2]};
+    if (A.xforms) apply_xform(A.xforms[find_molecule(A.offsets, A.B, al)], p[0], p[1], p[2]); // (8 dependent loads: only when needed)
     else if (A.xf_one.flags) apply_xform(A.xf_one, p[0], p[1], p[2]); // one molecule: its transform came with the launch
     float rmax32 = 0.0f;
     double rmax64 = 0.0;
@@ -456,20 +468,34 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs A) {
     }
     AtomRec R;
     uint32_t rng[3];
-    const bool keep = prep_atom(A, a, p, rmax32, rmax64, R, rng);
-    {   // non-temporal: records are not re-read by this XCD; kept out of L2 they cost the voxelize kernel 2.4 % less
+    const bool keep = prep_atom(A, al, p, rmax32, rmax64, R, rng);
+    {   // Records leave through LDS so that a store instruction writes 1 KB of consecutive bytes: straight from the
+        // registers it wrote 64 pieces of 16 B, 64 B apart (eight partial writes per 128-B line; WRITE_SIZE was 1.5 x
+        // the bytes stored and the kernel store-bound). Piece i of record r sits at stage[i * PITCH + r]: writes
+        // (consecutive r) and reads (16 lanes = four records x four pieces) are both bank-conflict free.
+        // Non-temporal: records are not re-read by this XCD; kept out of L2 they cost the voxelize kernel 2.4 % less.
         typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        constexpr int PITCH = 260;
+        __shared__ u4v stage[4 * PITCH];
         const u4v *src = reinterpret_cast<const u4v *>(&R);
-        u4v *dstv = reinterpret_cast<u4v *>(A.rec + a);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(src[i], dstv + i);
+        for (int i = 0; i < 4; ++i) stage[i * PITCH + threadIdx.x] = src[i];
+        __syncthreads();
+        const int64_t first = A.first + (int64_t)blockIdx.x * 256;
+        const int nrec = (int)((A.total - first) < 256 ? (A.total - first) : 256);
+        u4v *dstv = reinterpret_cast<u4v *>(A.rec + first);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int slot = k * 256 + threadIdx.x, r = slot >> 2, i = slot & 3;
+            if (r < nrec) __builtin_nontemporal_store(stage[i * PITCH + r], dstv + slot);
+        }
     }
     // y range in SUBY-voxel slabs (lo | hi << 8), z range in SUBZ-voxel sub-tiles (lo << 16 | hi << 24); a dropped
     // atom matches no slab (EMPTY_ENTRY)
     const uint32_t packed = !keep ? EMPTY_ENTRY
                                   : ((rng[1] & 0xffff) >> SUBY_SH) | (((rng[1] >> 16) >> SUBY_SH) << 8) |
                                         (((rng[2] & 0xffff) >> SUBZ_SH) << 16) | (((rng[2] >> 16) >> SUBZ_SH) << 24);
-    A.xp[a] = make_uint2(rng[0], packed);
+    if (live) A.xp[a] = make_uint2(rng[0], packed);
 }
 
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s) {
