@@ -211,7 +211,11 @@ int mvx_debug_read_records(mvx_handle *h, void *host_dst, int64_t n, void *strea
  *   "max_ct" = 1..32: upper bound on the channels one workgroup accumulates (more channel chunks);
  *   "direct" = 1 / 0 / -1: always / never / automatically take the single-launch per-molecule kernel (float32 grids);
  *   "mall_budget_kb" = k: cut batches into chunks of at most k KiB of pre-pass data (production: 288 MB, sized for
- *              the 256 MiB Infinity Cache), so that small test batches exercise the chunk-by-chunk launch order. */
+ *              the 256 MiB Infinity Cache), so that small test batches exercise the chunk-by-chunk launch order;
+ *   "max_ct64" = 16 | 32: float64 grids: channels one workgroup accumulates (default 32: Gaussian grids of more than
+ *              16 channels take 32 per workgroup on 4-wave slabs; 16 = the two-chunk form every other grid uses);
+ *   "nw" = 1..16: waves (8-voxel z sub-tiles) per slab instead of the plan's (0 = the plan); measurement aid;
+ *   "dense_grid" = k: workgroups of the voxelize_dense_kernel launch (0 = 512); measurement aid. */
 int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value);
 #ifdef __cplusplus
 }
