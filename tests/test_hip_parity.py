@@ -381,6 +381,28 @@ def test_binning_of_one_large_molecule_at_every_chunk_configuration(mv, n):
         assert_gaussian(binned, c_oracle.voxelize(xyz, f, r, dimension=D, sigma=0.8, radii_type="atom-wise"))
 
 
+@pytest.mark.parametrize("D,B", [(96, 1), (100, 1), (100, 3), (128, 2)])
+def test_binning_of_large_molecules_on_grids_with_many_slabs_per_x_slab(mv, D, B):
+    """Grids above 64 voxels have several slabs per z row and 48-64 slabs per x-slab: one or a few large molecules take
+    the 1024-thread binning configuration with one line per wave and several blocks per x-slab (B = 1) or four lines
+    per wave (small batches); 100 is not a multiple of the slab sizes. Binned route against the direct kernel bit for
+    bit, molecule 0 against the oracle."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(1000 * D + B)
+    W_ = 0.5 * (D - 1)
+    n = 3000
+    xyz = [rng.uniform(-W_ / 2 - 1, W_ / 2 + 1, (n, 3)) for _ in range(B)]
+    f = [rng.random((n, 4)).astype(np.float32) for _ in range(B)]
+    off = np.arange(B + 1, dtype=np.int64) * n
+    v = mv.create_voxelizer(0.5, D, "scalar", "gaussian", "hip", output="numpy", sigma=0.7)
+    v.debug_option("direct", 0)
+    binned = v.forward_batch(np.concatenate(xyz), off, None, np.concatenate(f), 1.4).copy()
+    v.debug_option("direct", 1)
+    assert np.array_equal(v.forward_batch(np.concatenate(xyz), off, None, np.concatenate(f), 1.4), binned)
+    assert_gaussian(binned[0], c_oracle.voxelize(xyz[0], f[0], 1.4, dimension=D, sigma=0.7))
+
+
 def test_ragged_batch_with_one_large_molecule(mv):
     """Packed x-list regions: a 5000-atom molecule next to tiny ones in one launch."""
     from oracle import c_oracle
