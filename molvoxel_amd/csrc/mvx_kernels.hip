@@ -544,11 +544,14 @@ constexpr int LINE_CAP = SLOTS + EXT_SLOTS - 1; // candidates a slab can hold be
 constexpr unsigned LINE_OVERFLOW = 0xffffffffu;
 static_assert(SLOTS == SLAB_LINE_ENTRIES && EXT_SLOTS == SLAB_EXT_ENTRIES, "slab line sizes are shared with the host side");
 
-// THREADS = 256, or 64 (one wave per block) for batches of small molecules: the same passes with a quarter of the
-// waves, which is what 4096 blocks of a ligand batch are bound by; or 1024 for a single large molecule, where the
-// kernel is a chain of latencies on a mostly idle chip: CH chunks of THREADS atoms are requested per round of pass A
-// (8 x 1024: the 10 000 atoms of cfg-5 are all in flight at once; with 256 threads and 4 chunks it took ten rounds of
-// one exposed memory latency each, 13 of the kernel's 20 us), and each of the 16 waves builds NQ = 1 line per pass.
+// Configurations (launch_xbin): THREADS = 256 for batches (8 blocks per compute unit; CH = 4 / 8 / 16 chunks of 64 atoms
+// per wave and round, so that molecules of up to 4 096 atoms need one round of pass A; NQ = 4 lines per wave and sweep);
+// 64 (one wave per block) for batches of small molecules: the same passes with a quarter of the waves, which is what
+// the 4 096 blocks of a ligand batch are bound by; 1 024 for one or a few large molecules, where the kernel is a chain
+// of latencies on a mostly idle chip: every key of the molecule is requested at once (CH up to 16 x 1 024 atoms; with
+// 256 threads and 4 chunks the 10 000 atoms of cfg-5 took ten rounds of one exposed memory latency each, 13 of the
+// kernel's 20 us), the whole x-list stays in LDS (XLN), and each of the 16 waves builds NQ = 1 line per sweep (several
+// blocks per x-slab) or, for small batches, NQ = 4 (one block per (molecule, x-slab)).
 template <int THREADS, int XLN, int CH, int NQ>
 __global__ void __launch_bounds__(THREADS)
     xbin_kernel(const uint2 *__restrict__ xp, const int64_t *__restrict__ offsets, int64_t n_one, int b0, int nsx, int nsy, int nzc, int NW,
@@ -567,9 +570,6 @@ __global__ void __launch_bounds__(THREADS)
     uint2 *dst = xlist + ((size_t)a0 + 2 * (size_t)b) * nsx + (size_t)sx * (size_t)(a1 - a0 + XL_HEADER);
     int count = 0, phase = 0;
     XB_STAMP(0);
-    // CH chunks of THREADS atoms per round; the next round's loads are issued before this round's barrier. Loads past
-    // the molecule are clamped to its last atom and masked by value (a select between a global and a private
-    // address would turn them into flat loads).
     if (a1 > a0) {
         // A round takes nch <= CH chunks of 64 consecutive atoms per wave (the last round only as many as are left):
         // wave w owns atoms [64*nch*w, 64*nch*(w+1)) of the round, so list order = atom order needs only one number per
@@ -590,11 +590,11 @@ __global__ void __launch_bounds__(THREADS)
         };
         auto round = [&](const uint2 (&v)[CH], const int rbase) {
             const int nch = chunks_of(rbase), first = rbase + wave * nch * 64 + lane;
-            // this wave's atoms of the round end at rend (chunks u >= nch would reach into the next wave's). The three
-            // conditions - an atom of this wave, x range reaches the slab from below
-            // and from above - are differences that must all be non-negative: one vector comparison of their OR gives the
-            // ballot mask directly (a conjunction of three comparisons is three masks and two scalar ANDs, and this
-            // kernel is bound by the scalar unit: 680 scalar against 480 vector instructions per wave at 256 molecules)
+            // This wave's atoms of the round end at rend (chunks u >= nch would reach into the next wave's). The three
+            // conditions - an atom of this wave, x range reaching the slab from below and from above - are differences
+            // that must all be non-negative: one vector comparison of their OR gives the ballot mask directly (a
+            // conjunction of three comparisons is three masks and two scalar ANDs, and this kernel is bound by the scalar
+            // unit: 680 scalar against 480 vector instructions per wave at 256 molecules).
             const int wend = rbase + (wave + 1) * nch * 64, rend = wend < n ? wend : n;
             bool m[CH];
             int cnt[CH], own = 0;
