@@ -667,8 +667,9 @@ int run(mvx_handle *h, const RunArgs &r) {
             // the bracket holds voxelize_kernel alone (what rocprofv3 reports under that name)
             if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, ct, gauss, chanwise, lane_range, s); }))) return rc;
         }
-        // a slab overflows at min(8 NW, 64) candidates: impossible when no molecule has that many atoms
-        if (max_atoms >= std::min(8 * sp.NW, 64)) HIP_TRY(launch_voxelize_dense(va, ct, gauss, chanwise, lane_range, s));
+        // a slab is left to the dense kernel only beyond line + extension (255 candidates): impossible when no molecule
+        // has that many atoms
+        if (max_atoms > SLAB_LINE_ENTRIES + SLAB_EXT_ENTRIES - 1) HIP_TRY(launch_voxelize_dense(va, ct, gauss, chanwise, lane_range, s));
     }
 
     if (overlap) { // the next call but one refills this set

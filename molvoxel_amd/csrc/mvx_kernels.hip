@@ -1259,10 +1259,12 @@ __device__ __forceinline__ void line_round(typename Ops::Acc &acc, const uint2 E
 // profiles/r02_phase_timelines.txt). The z sub-tile filter reads the admitted z range from the staged records instead
 // of the line's packed copy (same bits: both come from prep_atom's range, in SUBZ-voxel units).
 template <typename Ops>
-__device__ __forceinline__ void line_round_scalar(typename Ops::Acc &acc, const uint2 *__restrict__ line, int n_line, int RW,
-                                                  unsigned *un, const unsigned *__restrict__ rec, const unsigned *__restrict__ w,
-                                                  int64_t a0, int lane, int wave, int NW, const LaneCtx &L, const VoxParams &P,
-                                                  const double *__restrict__ Tc, const float *__restrict__ kc) {
+__device__ __forceinline__ void line_round_scalar(typename Ops::Acc &acc, const uint2 *__restrict__ line, const uint2 *__restrict__ ext,
+                                                  int e0, int n_line, int RW, unsigned *un, const unsigned *__restrict__ rec,
+                                                  const unsigned *__restrict__ w, int64_t a0, int lane, int wave, int NW, const LaneCtx &L,
+                                                  const VoxParams &P, const double *__restrict__ Tc, const float *__restrict__ kc) {
+    // round e0 / RW of the slab's candidates: row slot sl holds entry e0 + sl of the line (entries 1..n_line; entry e sits
+    // at line[e] up to SLOTS-1 and at ext[e - SLOTS] beyond)
     constexpr int SW = Ops::SW;
     const unsigned *src = lane < 16 ? rec + lane : w + (Ops::WORDS * L.cbase + lane - 16);
     const size_t stride = lane < 16 ? (size_t)16 : (size_t)(Ops::WORDS * P.w_stride);
@@ -1270,26 +1272,26 @@ __device__ __forceinline__ void line_round_scalar(typename Ops::Acc &acc, const 
     int ai[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) { // eight independent scalar loads
-        const int sl = wave + u * NW;
-        ai[u] = (sl >= 1 && sl <= n_line) ? (int)line[sl].x : 0;
+        const int e = e0 + wave + u * NW;
+        ai[u] = (e >= 1 && e <= n_line) ? (int)(e < SLOTS ? line[e].x : ext[e - SLOTS].x) : 0;
     }
     unsigned v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int sl = wave + u * NW;
+        const int e = e0 + wave + u * NW;
         v[u] = 0u;
-        if (sl >= 1 && sl <= n_line && stager) v[u] = src[(size_t)(a0 + ai[u]) * stride];
+        if (e >= 1 && e <= n_line && stager) v[u] = src[(size_t)(a0 + ai[u]) * stride];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int sl = wave + u * NW;
-        if (sl >= 1 && sl <= n_line && stager) un[sl * SW + lane] = v[u];
+        const int sl = wave + u * NW, e = e0 + sl;
+        if (e >= 1 && e <= n_line && stager) un[sl * SW + lane] = v[u];
     }
     VK_STAMP(2);
     __syncthreads();
     VK_STAMP(3);
     bool ok = false;
-    if (lane >= 1 && lane <= n_line) {
+    if (lane < RW && e0 + lane >= 1 && e0 + lane <= n_line) {
         const unsigned zr = un[lane * SW + 12];
         ok = ((int)((zr & 0xffff) >> SUBZ_SH) <= L.zt_w) && ((int)((zr >> 16) >> SUBZ_SH) >= L.zt_w);
     }
@@ -1304,8 +1306,9 @@ __device__ __forceinline__ void line_round_scalar(typename Ops::Acc &acc, const 
 
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
-    voxelize_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist, const double *__restrict__ Tc,
-                    const float *__restrict__ kc, float *__restrict__ out, int *__restrict__ overflow, const VoxParams P) {
+    voxelize_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
+                    const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
+                    int *__restrict__ overflow, const VoxParams P) {
     typedef OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE> Ops;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1323,12 +1326,8 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     }
     b += P.b0;
     // the slab's candidate line: {count, first atom}, then {atom index, packed ranges} per candidate
-#ifdef MVX_VECTOR_LINE
-    const uint2 E = slist[((size_t)b * (size_t)gridDim.x + t) * SLOTS + lane];
-#else
     const uint2 *__restrict__ line = slist + ((size_t)b * (size_t)gridDim.x + t) * SLOTS; // (uniform: scalar loads)
     const uint2 hdr = line[0];
-#endif
     int sx, sy, zc;
     decode_slab(t, P, sx, sy, zc);
     const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
@@ -1338,27 +1337,28 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     Ops::zero(acc);
 
     VK_STAMP(0);
-#ifdef MVX_VECTOR_LINE
-    const unsigned n_hdr = (unsigned)__builtin_amdgcn_readlane((int)E.x, 0);
-    const int64_t a0 = (int64_t)(unsigned)__builtin_amdgcn_readlane((int)E.y, 0);
-#else
     const unsigned n_hdr = __builtin_amdgcn_readfirstlane(hdr.x);
     const int64_t a0 = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane(hdr.y);
-#endif
     VK_STAMP(1); // the line has arrived
-    const int RW = 8 * NW < 64 ? 8 * NW : 64; // rows this kernel can stage
-    if (n_hdr >= (unsigned)RW) { // includes LINE_OVERFLOW: dense slab, left to voxelize_dense_kernel
+    const int RW = 8 * NW < 64 ? 8 * NW : 64; // rows staged per round
+    if (n_hdr > (unsigned)LINE_CAP) { // LINE_OVERFLOW: more candidates than line + extension hold, left to voxelize_dense_kernel
         if (tid == 0) {
             const int pos = atomicAdd(overflow, 1);
             overflow[1 + pos] = (int)((unsigned)(b * P.ncc + cc) * gridDim.x + t);
         }
         return;
     }
-#ifdef MVX_VECTOR_LINE
-    if (n_hdr > 0) line_round<Ops>(acc, E, 0, (int)n_hdr, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
-#else
-    if (n_hdr > 0) line_round_scalar<Ops>(acc, line, (int)n_hdr, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
-#endif
+    if (n_hdr > 0) {
+        const uint2 *__restrict__ ext = slist_ext + ((size_t)b * (size_t)gridDim.x + t) * EXT_SLOTS;
+        line_round_scalar<Ops>(acc, line, ext, 0, (int)n_hdr, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
+        // more candidates than one round of rows (dense slabs: larger radii): further rounds over the line and its
+        // extension, the accumulators carried along. (Round 1 sent such slabs to voxelize_dense_kernel's two workgroups
+        // per compute unit: with a 1.5 A radius on cfg-2 that launch took 230 of the step's 618 us.)
+        for (int e0 = RW; e0 <= (int)n_hdr; e0 += RW) {
+            __syncthreads(); // every wave is done with the previous round's rows
+            line_round_scalar<Ops>(acc, line, ext, e0, (int)n_hdr, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
+        }
+    }
     Ops::write(acc, n_hdr > 0, un, tid, lane, wave, NW, b, L, x0, y0, z0, out, P);
     VK_STAMP(6); // all stores issued
 #ifdef MVX_DIAG
@@ -2051,7 +2051,7 @@ struct LaunchFn {
         hipError_t e = raise_lds_limit(kern, lds, raised);
         if (e != hipSuccess) return e;
         launch_profiled(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), lds, s, a.rec, a.w,
-                        a.slist, a.Tc, a.kc, static_cast<float *>(a.out), a.overflow, a.p);
+                        a.slist, a.slist_ext, a.Tc, a.kc, static_cast<float *>(a.out), a.overflow, a.p);
         return hipGetLastError();
     }
 };
@@ -2061,6 +2061,10 @@ struct DenseFn {
     hipStream_t s;
     template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
     hipError_t operator()() const {
+#ifdef MVX_DENSE_WPE
+        if (a.p.NW <= 8)
+            return launch_dense<OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE>, 512, MVX_DENSE_WPE>(a, a.overflow, dense_lds_bytes(CT, a.p.NW), a.dense_grid ? a.dense_grid : 512u, 0u, s);
+#endif
         return launch_dense<OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE>>(a, a.overflow, dense_lds_bytes(CT, a.p.NW), a.dense_grid ? a.dense_grid : 512u, 0u, s);
     }
 };
