@@ -815,21 +815,24 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
 // voxel per lane, CT channel accumulators per lane in registers. Every output byte is written exactly once (zeros
 // included) with 16-B/lane non-temporal stores in whole-row runs; no atomics, no memset, no MFMA.
 //
-// voxelize_kernel (the normal case: the slab's primary line holds all its candidates, <= 63).
+// voxelize_kernel (built for the normal case: the slab's primary line holds all its candidates, <= 63).
 //   grid = (slab id, molecule * ncc + channel chunk), one workgroup per slab:
-//     1. every wave loads the slab's 512-B candidate line (lane l = entry l; entry 0 = {count, first atom});
+//     1. every wave reads the line's header {count, first atom} and the atom indices of the <= 8 row slots it stages
+//        through the scalar path;
 //     2. stage: wave w copies the rows of candidates w, w+NW, ... (64-B record + CT channel weights, one coalesced
-//        load each, indices by v_readlane, all loads in flight at once) into LDS; one barrier;
-//     3. walk: each wave picks the candidates whose z range touches its sub-tile straight from the line it holds in
-//        registers (ballot) and processes them: broadcast LDS reads, fp64 d2 in cdist order, compare with T, exp2,
+//        load each, all loads in flight at once) into LDS; one barrier;
+//     3. walk: each wave picks the candidates whose z range touches its sub-tile from the staged records (one lane per
+//        row + ballot) and processes them: broadcast LDS reads, fp64 d2 in cdist order, compare with T, exp2,
 //        software-pipelined weight reads + packed FMAs;
 //     4. write-out: accumulators -> LDS tile (CR = min(CT, MVX_CR = 4) channels per round) -> stores. Empty slabs skip the
 //        LDS round trip.
-//   A slab with more candidates only appends its id to the overflow list and leaves.
-// voxelize_dense_kernel (dense clusters; usually the list is empty and the launch returns at once): a fixed grid
-//   loops over the overflow list. Per slab: rounds of 64 entries over the primary + extension line (<= 255
-//   candidates), or, beyond that, wave 0 compacts the (molecule, x-slab) list in rounds of LCAP entries into an
-//   LDS list and the rows are staged in rounds of dcap; same walk and write-out.
+//   A slab with 64..255 candidates repeats 1-3 over the rest of the line and its extension (rounds of 64 rows, the
+//   accumulators carried along); only a slab beyond that (LINE_OVERFLOW) appends its id to the overflow list and leaves.
+// voxelize_dense_kernel (the general slab loop; float32: over the overflow list, usually empty - then the launch returns
+//   at once, and it is not launched at all when no molecule has more than 255 atoms; float64 grids: over all slabs).
+//   Per slab: rounds of 64 entries over the primary + extension line (<= 255 candidates), or, beyond that, wave 0
+//   compacts the (molecule, x-slab) list in rounds of LCAP entries into an LDS list and the rows are staged in rounds
+//   of dcap; same walk and write-out.
 // LDS map (dynamic, 16-B aligned): voxelize_kernel: union { 64 x SW words of rows ; (CR*RPC rows) x RS floats tile };
 //   dense kernel: int list[LCAP] | uint32 zr[LCAP] | int nlist | union { dcap rows ; tile }, LCAP = 64 * min(NW, 4).
 
