@@ -2064,10 +2064,6 @@ struct DenseFn {
     hipStream_t s;
     template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
     hipError_t operator()() const {
-#ifdef MVX_DENSE_WPE
-        if (a.p.NW <= 8)
-            return launch_dense<OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE>, 512, MVX_DENSE_WPE>(a, a.overflow, dense_lds_bytes(CT, a.p.NW), a.dense_grid ? a.dense_grid : 512u, 0u, s);
-#endif
         return launch_dense<OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE>>(a, a.overflow, dense_lds_bytes(CT, a.p.NW), a.dense_grid ? a.dense_grid : 512u, 0u, s);
     }
 };
