@@ -403,6 +403,30 @@ def test_binning_of_large_molecules_on_grids_with_many_slabs_per_x_slab(mv, D, B
     assert_gaussian(binned[0], c_oracle.voxelize(xyz[0], f[0], 1.4, dimension=D, sigma=0.7))
 
 
+@pytest.mark.parametrize("D", [18, 50])
+def test_even_dimension_that_is_not_a_multiple_of_four(mv, D):
+    """Rows of such grids start on 8-byte, not 16-byte, boundaries: the write-out takes the element-by-element path
+    (both routes, a slice of a batch grid as out_grid included)."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(D)
+    W_ = 0.5 * (D - 1)
+    n = 700
+    xyz = rng.uniform(-W_ / 2 - 1, W_ / 2 + 1, (n, 3))
+    f = rng.random((n, 5)).astype(np.float32)
+    ref = c_oracle.voxelize(xyz, f, 1.1, dimension=D)
+    v = mv.create_voxelizer(0.5, D, "scalar", "gaussian", "hip")
+    grid = v.get_empty_grid(5, batch_size=3)
+    dx, df = v.asarray(xyz, "coords"), v.asarray(f, "features")
+    for route in (0, 1):
+        v.debug_option("direct", route)
+        grid.fill_(7.0)
+        out = v.forward(dx, None, df, 1.1, out_grid=grid[1])
+        assert out.data_ptr() == grid[1].data_ptr()
+        assert_gaussian(out.cpu().numpy(), ref)
+        assert float(grid[0].min()) == 7.0 and float(grid[2].max()) == 7.0  # neighbours untouched
+
+
 def test_ragged_batch_with_one_large_molecule(mv):
     """Packed x-list regions: a 5000-atom molecule next to tiny ones in one launch."""
     from oracle import c_oracle
