@@ -764,7 +764,6 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
     // several blocks per (molecule, x-slab), each repeating the cheap pass A, until ~2048 blocks are in flight
     int parts = 1;
     while (parts * 16 < nslab && (long long)nb * nsx * parts < 2048) parts *= 2;
-#ifndef MVX_XBIN_NO_BIG
     // Large molecules, few of them (at most two 1024-thread blocks per compute unit): latency is all there is. One
     // block per (molecule, x-slab) with four lines per wave when that already gives >= 256 blocks (pass A runs once per
     // pair), else one line per wave and nslab/16 blocks per pair (each repeats pass A on an otherwise idle unit).
@@ -794,7 +793,6 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
             return hipGetLastError();
         }
     }
-#endif
     // chunks per round: one round of pass A (one barrier, one exchange of counts) for molecules of up to 4 096 atoms
     // (cfg-2, 256 molecules: 56.4 us with 4 chunks = four rounds, 50.7 with 8, 48.6 with 16)
     const dim3 grid((unsigned)(nb * nsx), (unsigned)parts);
