@@ -143,6 +143,8 @@ def main():
                          "are HBM-resident and complete before the loop, which is that mode's contract); 0: serial calls")
     args = ap.parse_args()
 
+    # (RCCL between the ranks of one node needs dmabuf IPC on this driver stack; the pool exports this already)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
