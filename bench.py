@@ -2,7 +2,8 @@
 """Headline benchmark: forward_features, C=32, 64^3, N=4000 (BASELINE.json configs[1]) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, or bare -
+    bench.py then starts that launcher itself as a child process, before it touches torch or the GPU)
 
 A step is one pass of the hot path over one batch of `--batch` synthetic cfg-2 molecules per GPU
 (one mvx_forward_features_batch call: prep kernel + voxelize kernel), inputs already resident in
@@ -70,7 +71,7 @@ def cpu_baseline(budget_s: float):
                 sample=f"{n} calls of oracle/numpy_port.voxelize (numpy {np.__version__} + scipy cdist/BLAS, the "
                        f"reference's block algorithm) on the seed-0 cfg-2 molecule in {el:.1f} s; "
                        f"os.cpu_count()={os.cpu_count()}, BLAS threads={blas_threads}")
-    # all-core C/OpenMP restatement of the same rule (fairest CPU number), reported alongside
+    # all-core C/OpenMP restatement of the same rule ((x-plane, y-band) tiles, ~4 per thread), reported alongside
     c_oracle.voxelize(xyz, feat, 1.0, dimension=64, out=out)
     m, t0 = 0, time.perf_counter()
     while True:
@@ -86,8 +87,8 @@ def cpu_baseline(budget_s: float):
 
 def parity_spot(out, coords, feats, picks, radius=1.0, dimension=64, sigma=0.5):
     """Post-timing spot check (outside the timed region): the grids of the molecules `picks` of the batch that was
-    just timed against the CPU oracle: membership identical, |d| <= 5e-6 * max(1, |ref|) per voxel
-    (tests/tolerance.py). Returns "ok" or "FAIL: ..."."""
+    just timed against the CPU oracle: membership identical, |d| <= 1e-5 absolute on every voxel (the north-star bar,
+    tests/tolerance.py). Returns "ok" or "FAIL: ..."."""
     from oracle import c_oracle
 
     for b in picks:
@@ -96,9 +97,9 @@ def parity_spot(out, coords, feats, picks, radius=1.0, dimension=64, sigma=0.5):
         bad = int(np.not_equal(got != 0, ref != 0).sum())
         if bad:
             return f"FAIL: molecule {b}: membership differs in {bad} voxels"
-        ex = float((np.abs(got - ref) / (5e-6 * np.maximum(1.0, np.abs(ref)))).max())
-        if ex > 1.0:
-            return f"FAIL: molecule {b}: error {ex:.3g} x the tolerance"
+        worst = float(np.abs(got - ref).max())
+        if worst > 1e-5:
+            return f"FAIL: molecule {b}: max |out - ref| = {worst:.3g} > 1e-5"
     return "ok"
 
 
@@ -127,12 +128,145 @@ def make_cfg4_shard(total: int, rank: int, world: int):
     return wl, lo, hi
 
 
+PREWARM_LAUNCHES = 30  # fixed, disclosed in the JSON line: the clock ramp after an idle period lasts ~15 launches
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def self_launch(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (this process has
+    not touched torch or the GPU yet and never will), relay rank 0's single JSON line, return the child's exit code."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)  # stderr passes straight through
+    lines = []
+    for ln in proc.stdout:
+        if ln.startswith("{"):
+            lines.append(ln.rstrip("\n"))
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    for ln in lines:
+        print(ln, flush=True)
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write(f"bench.py: expected one JSON line from rank 0, saw {len(lines)}\n")
+        return 3
+    return rc
+
+
+class Ranks:
+    """The only things the ranks share: a barrier, the MAX of the elapsed time and a gather of per-rank figures.
+    gloo is always there (CPU, cannot fail on a GPU quirk); when every rank has its own GPU the barrier and the MAX go
+    over RCCL ("nccl"), agreed on over gloo so that a rank whose RCCL setup failed cannot leave the others waiting."""
+
+    def __init__(self, world: int, rank: int, device, own_gpu: bool):
+        self.world, self.rank, self.device = world, rank, device
+        self.dist, self.nccl, self.backend, self.note = None, None, None, None
+        if world == 1:
+            return
+        import datetime
+
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        self.dist, self.backend = dist, "gloo"
+        if own_gpu:
+            ok, why = 1, ""
+            try:
+                grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe, group=grp)
+                torch.cuda.synchronize()
+                ok = int(probe.item() == world)
+            except Exception as exc:  # RCCL unusable here: the gloo group carries the barrier instead
+                ok, why = 0, f"{type(exc).__name__}: {exc}"[:200]
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                self.nccl, self.backend = grp, "nccl"
+            else:
+                self.note = why or "RCCL set-up failed on another rank"
+
+    def barrier(self):
+        if self.dist is None:
+            return
+        if self.nccl is not None:
+            import torch
+
+            t = torch.zeros(1, device=self.device)
+            self.dist.all_reduce(t, group=self.nccl)
+            torch.cuda.synchronize()
+        else:
+            self.dist.barrier()
+
+    def max_and_gather(self, x: float):
+        """(max over ranks, list of every rank's value, number of ranks that answered)"""
+        if self.dist is None:
+            return x, [x], 1
+        import torch
+
+        if self.nccl is not None:
+            t = torch.tensor([x], dtype=torch.float64, device=self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.nccl)
+            mx = float(t.item())
+        else:
+            t = torch.tensor([x], dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            mx = float(t.item())
+        every = [torch.zeros(1, dtype=torch.float64) for _ in range(self.world)]
+        self.dist.all_gather(every, torch.tensor([x], dtype=torch.float64))
+        seen = torch.ones(1, dtype=torch.int64)
+        self.dist.all_reduce(seen)
+        return mx, [float(v.item()) for v in every], int(seen.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def rehearse(args, world: int, rank: int) -> None:
+    """--rehearse: the launcher plumbing of an N-rank run with NO GPU work (for boxes with fewer GPUs than ranks and for
+    the CPU test suite): rendezvous, barrier, MAX over ranks, gather, one JSON line from rank 0. Not a measurement."""
+    ranks = Ranks(world, rank, None, own_gpu=False)
+    acc = np.zeros(1024)
+    for _ in range(args.warmup):
+        acc += 1.0
+    ranks.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        acc += 1.0
+    ranks.barrier()
+    elapsed, rank_s, seen = ranks.max_and_gather(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL of the launcher plumbing - no GPU work, not a measurement", "value": 0.0,
+                          "unit": "molecules/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "none", "rehearsal": True, "ranks_seen": seen,
+                          "collective_backend": ranks.backend, "config": {"workload": "none (plumbing rehearsal)"},
+                          "rank_ms_per_step": {"min": 1e3 * min(rank_s) / max(1, args.steps),
+                                               "max": 1e3 * max(rank_s) / max(1, args.steps)}}), flush=True)
+    ranks.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=20,
-                    help="untimed steps; the first ~15 launches after an idle period run up to 18 %% slower (clock ramp)")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps before the timed ones (after the fixed pre-warm)")
     ap.add_argument("--workload", choices=("cfg2", "cfg4"), default="cfg2",
                     help="cfg2 = the headline metric (default); cfg4 = 1024 ligands x world size, sharded by atom count")
     ap.add_argument("--batch", type=int, default=256, help="cfg-2 molecules per GPU per step (8.6 GB of grids at 256)")
@@ -141,30 +275,36 @@ def main():
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: mvx_set_overlap - the pre-pass of step k+1 runs under the voxelize launch of step k (the inputs "
                          "are HBM-resident and complete before the loop, which is that mode's contract); 0: serial calls")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="plumbing only: launcher, rendezvous, barrier, MAX, one JSON line - no GPU work, not a measurement")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with no launcher around it: become the launcher. This happens before torch is imported
+    # or the GPU is touched, and the ranks are children - nothing is re-executed.
+    if args.gpus > 1 and ("WORLD_SIZE" not in os.environ or "RANK" not in os.environ):
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; start it as `python bench.py "
+                         f"--gpus {args.gpus}` (it launches its own ranks) or under torch.distributed.run with "
+                         f"--nproc-per-node {args.gpus}\n")
+        sys.exit(2)
+    if args.rehearse:
+        return rehearse(args, world, rank)
 
     # (RCCL between the ranks of one node needs dmabuf IPC on this driver stack; the pool exports this already)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
     ndev = torch.cuda.device_count()
     # one GPU per rank is the real layout; with fewer GPUs than ranks (rehearsal on a 1-GPU box) ranks share devices
     # and the barrier runs over gloo, because RCCL refuses two ranks on one device
     dev_index = local_rank if ndev >= world else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if ndev >= world:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+    ranks = Ranks(world, rank, torch.device("cuda", dev_index), own_gpu=ndev >= world)
 
     import molvoxel_amd
 
@@ -195,35 +335,40 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        ranks.barrier()
         torch.cuda.synchronize()
 
-    # (event creation takes milliseconds of host time: done before the warm-up, so that the GPU does not sit idle -
-    # and drop its clock - between the warm-up and the timed steps)
-    vox.set_profiling(True)
+    # Pass 1 - what `value` and `ms_per_step` come from: no profiling events anywhere near the launches.
+    # A fixed pre-warm precedes the counted warm-up: the first ~15 launches after an idle period run up to 18 % slower
+    # (clock ramp), and a caller's small --warmup should not decide whether the timed steps sit on that ramp.
+    for _ in range(PREWARM_LAUNCHES):
+        step()
     for _ in range(args.warmup):
         step()
     barrier()
-    vox.read_kernel_times_ms()  # discard the warm-up launches
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    my_elapsed = time.perf_counter() - t0
+    elapsed, rank_s, ranks_seen = ranks.max_and_gather(my_elapsed)
+    rank_ms = [1e3 * s / args.steps for s in rank_s]
+
+    # Pass 2 - the same K steps again, back to back, with the library's HIP events around the voxelize launch (recorded on
+    # the launch stream): the kernel durations the roofline figure is built from. The events cost ~11 us of idle GPU per
+    # step, which is why this pass does not feed `value`.
+    vox.set_profiling(True)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    vox.read_kernel_times_ms()  # discard
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    profiled_ms_per_step = 1e3 * (time.perf_counter() - t1) / args.steps
     kernel_ms = vox.read_kernel_times_ms()
     vox.set_profiling(False)
-    my_elapsed = elapsed
-
-    rank_ms = [1e3 * my_elapsed / args.steps]
-    if dist is not None:
-        on = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=on)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        allms = [torch.zeros(1, dtype=torch.float64, device=on) for _ in range(world)]
-        dist.all_gather(allms, torch.tensor([1e3 * my_elapsed / args.steps], dtype=torch.float64, device=on))
-        rank_ms = [float(x.item()) for x in allms]
 
     # post-timing spot check of the grids the timed steps left behind (rank 0, outside the timed region)
     spot = None
@@ -248,8 +393,11 @@ def main():
             "value": job_molecules * args.steps / elapsed,
             "unit": "molecules/s",
             "n_gpus": args.gpus,
+            "ranks_seen": ranks_seen,
+            "collective_backend": ranks.backend,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_launches": PREWARM_LAUNCHES,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
@@ -262,7 +410,8 @@ def main():
                 "inputs": "HBM-resident (torch CUDA tensors), outputs left in HBM",
                 "prepass_overlap": bool(args.overlap),
                 "geometry_dtype": "f64",
-                "parallelism": f"{args.gpus} independent ranks, molecules sharded, no collective",
+                "parallelism": f"{args.gpus} independent ranks, molecules sharded, no collective on the data path",
+                "gpus_visible_per_rank": ndev,
             },
             "roofline": {
                 "bound": "hbm",
@@ -277,6 +426,9 @@ def main():
                 "kernel_ms_p50": float(k[len(k) // 2]),
                 "kernel_ms_max": float(k[-1]),
                 "kernel_ms_list": [round(float(x), 4) for x in kernel_ms],
+                "kernel_ms_source": f"pass 2: the same {args.steps} steps repeated right after the timed ones with HIP events "
+                                    "around the voxelize launch on its stream (mvx_set_profiling); `value` is pass 1, no events",
+                "profiled_pass_ms_per_step": profiled_ms_per_step,
                 "kernel_launches_timed": len(kernel_ms),
                 "launches_per_step": lps,
                 "molecules_per_launch": B // lps,
@@ -289,12 +441,12 @@ def main():
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
             "parity_spot": spot,
         }
+        if ranks.note:
+            res["collective_note"] = ranks.note
         if args.gpus == 1 and args.cpu_seconds > 0 and args.workload == "cfg2":
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -211,13 +211,10 @@ struct RunArgs {
 int adopt_stream(mvx_handle *h, hipStream_t s) {
     if (h->used && h->last_stream != s) {
         if (!h->ev_switch) HIP_TRY(hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming));
-        // a stream the caller has destroyed meanwhile cannot be recorded on: fall back to a device-wide wait
-        if (hipEventRecord(h->ev_switch, h->last_stream) == hipSuccess) {
-            HIP_TRY(hipStreamWaitEvent(s, h->ev_switch, 0));
-        } else {
-            (void)hipGetLastError();
-            HIP_TRY(hipDeviceSynchronize());
-        }
+        // (the previous stream is alive by contract - mvx.h: "a stream must stay alive until the next call on the handle
+        // has returned"; a destroyed handle cannot be detected reliably, so nothing here pretends to)
+        HIP_TRY(hipEventRecord(h->ev_switch, h->last_stream));
+        HIP_TRY(hipStreamWaitEvent(s, h->ev_switch, 0));
     }
     h->last_stream = s;
     h->used = true;
@@ -434,7 +431,9 @@ int run(mvx_handle *h, const RunArgs &r) {
     if (forced_pipeline) nchunk = std::max(nchunk, h->pipeline);
     // Cross-call overlap (mvx_set_overlap): this call's pre-pass fills the other workspace set on the side stream,
     // under the previous call's voxelize launches. Device-resident inputs and outputs only.
-    const bool overlap = h->overlap && !direct && nchunk == 1 && !forced_pipeline && r.in_kind == MVX_DEVICE && r.out_kind == MVX_DEVICE;
+    // Batches only (mvx.h: "the batched three-launch path"): a per-molecule call hands over arrays its Python layer may
+    // have converted on the caller's stream a moment ago, which the side stream would not wait for.
+    const bool overlap = h->overlap && !direct && r.B > 1 && nchunk == 1 && !forced_pipeline && r.in_kind == MVX_DEVICE && r.out_kind == MVX_DEVICE;
     if (overlap) h->cur ^= 1;
     Workspace &w = h->ws[h->cur];
     // (the side stream only serves the "chunks" test option and mvx_set_overlap; chunks cut for the cache, or for the
@@ -940,7 +939,7 @@ int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
     else if (n == "direct") h->direct_mode = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "max_ct64") h->max_ct64 = value >= 32 ? 32 : 16;
     else if (n == "dense_grid") h->dense_grid = value > 0 ? value : 0;
-    else if (n == "nw") h->force_nw = value; // waves (8-voxel z sub-tiles) per slab, 1..16; 0 = the default plan
+    else if (n == "nw") h->force_nw = (value >= 1 && value <= 16) ? value : 0; // waves (8-voxel z sub-tiles) per slab; 0 = the default plan
     else if (n == "mall_budget_kb") h->mall_budget = value > 0 ? 1024.0 * (double)value : MALL_BUDGET;
 #ifdef MVX_DIAG
     else if (n == "dbg") h->dbg = value;

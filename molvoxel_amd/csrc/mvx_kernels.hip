@@ -834,18 +834,25 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
 // LDS map (dynamic, 16-B aligned): voxelize_kernel: union { 64 x SW words of rows ; (CR*RPC rows) x RS floats tile };
 //   dense kernel: int list[LCAP] | uint32 zr[LCAP] | int nlist | union { dcap rows ; tile }, LCAP = 64 * min(NW, 4).
 
-// 16-B output store. kind 0: plain (line stays in the XCD's L2); 1: nt; 2: sc1 (write-through). Output bytes are
-// written once and never re-read here; nt keeps them from displacing the re-read inputs (0.69 -> 0.54 ms, cfg-2).
+// 16-B output store: non-temporal. Output bytes are written once and never re-read here; nt keeps them from displacing
+// the re-read inputs in L2 (0.69 -> 0.54 ms, cfg-2; sc1 = plain). A/B builds (make EXPERIMENT=1) pick the kind at run
+// time - 0: plain (line stays in the XCD's L2); 1: nt; 2: sc1 (write-through); the shipped kernels hold one store form.
 __device__ __forceinline__ void store_f4(float *dst, const float4 v, int kind) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 x = {v.x, v.y, v.z, v.w};
-    if (kind == 1) {
-        __builtin_nontemporal_store(x, reinterpret_cast<f4 *>(dst));
-    } else if (kind == 2) {
+#ifdef MVX_EXPERIMENT
+    if (kind == 2) {
         asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(x) : "memory");
-    } else {
-        *reinterpret_cast<f4 *>(dst) = x;
+        return;
     }
+    if (kind == 0) {
+        *reinterpret_cast<f4 *>(dst) = x;
+        return;
+    }
+#else
+    (void)kind;
+#endif
+    __builtin_nontemporal_store(x, reinterpret_cast<f4 *>(dst));
 }
 
 // floats per tile row: SUBZ*NW plus a pad that keeps ds_write_b32 conflict-free for the lane -> (row, column) map

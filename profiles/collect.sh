@@ -11,7 +11,12 @@ out=gpurun_out/profiles_$tag
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
 BATCH=${BATCH:-256}
-BENCH="python3 bench.py --cpu-seconds 0 --batch $BATCH"
+STEPS=${STEPS:-40}
+WARMUP=${WARMUP:-20}
+PREWARM=$(python3 -c "import bench; print(bench.PREWARM_LAUNCHES)")
+# explicit --steps / --warmup: the slices below are derived from these, never from bench.py's defaults.
+# Dispatch order of one run: PREWARM pre-warm + WARMUP warm-up + STEPS timed (pass 1, `value`) + 2 + STEPS (pass 2, events)
+BENCH="python3 bench.py --cpu-seconds 0 --batch $BATCH --steps $STEPS --warmup $WARMUP"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kernel_trace" -- $BENCH > "$out/kernel_trace.log" 2>&1 || echo "kernel-trace failed"
 i=0
 for grp in "WRITE_SIZE GRBM_GUI_ACTIVE" "FETCH_SIZE" \
@@ -20,9 +25,11 @@ for grp in "WRITE_SIZE GRBM_GUI_ACTIVE" "FETCH_SIZE" \
   i=$((i+1))
   rocprofv3 --pmc $grp --output-format csv -d "$out/pmc$i" -- $BENCH > "$out/pmc$i.log" 2>&1 || echo "pmc pass $i failed"
 done
-python3 - "$out" "$tag" "$BATCH" <<'PY'
+python3 - "$out" "$tag" "$BATCH" "$STEPS" "$WARMUP" "$PREWARM" <<'PY'
 import csv, glob, json, sys, collections, os
 out, tag, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
+steps, warmup, prewarm = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+calls_per_run = prewarm + warmup + steps + 2 + steps  # bench.py steps per run (each = launches_per_step dispatches)
 # kernel stats
 stats = []
 for f in glob.glob(out + "/kernel_trace/**/*kernel_stats.csv", recursive=True):
@@ -31,7 +38,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         agg[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-lines = [f"# rocprofv3 --kernel-trace --stats (python3 bench.py --cpu-seconds 0 --batch {batch}, defaults: 20 warm-up + 40 timed steps)"]
+lines = [f"# rocprofv3 --kernel-trace --stats (python3 bench.py --cpu-seconds 0 --batch {batch} --steps {steps} --warmup {warmup}: "
+         f"{prewarm} pre-warm + {warmup} warm-up + {steps} timed steps (pass 1) + 2 + {steps} steps with events (pass 2))"]
 for r in sorted(stats, key=lambda r: -float(r["TotalDurationNs"])):
     lines.append(f'{r["Name"][:110]:110s} calls={r["Calls"]:>4s} avg_ns={float(r["AverageNs"]):12.1f} pct={r["Percentage"]}')
 lines.append("")
@@ -44,27 +52,33 @@ for k, d in agg.items():
     if "voxelize_kernel" in k and "WRITE_SIZE" in d:
         wr = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"]) * 1024.0          # KB -> bytes (exact for 16-B/lane stores)
         rd = 2.0 * sum(d.get("FETCH_SIZE", [0])) / max(1, len(d.get("FETCH_SIZE", [0]))) * 1024.0  # gfx950: x2
-        summary = {"workload": "cfg2", "batch": batch, "steps_profiled": 60, "kernel": k[:80], "write_bytes_per_launch": wr,
+        summary = {"workload": "cfg2", "batch": batch, "steps_profiled": calls_per_run, "kernel": k[:80], "write_bytes_per_launch": wr,
                    "fetch_bytes_per_launch_corrected": rd, "hbm_bytes_per_launch": wr + rd, "tag": tag,
                    "note": "WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (MI355X_MICROARCH.md HBM section: FETCH_SIZE reads half on gfx950)"}
-        # per-dispatch durations: the last 40 launches are bench.py's timed steps (the 20 before them warm the clock up)
+        # per-dispatch durations, in dispatch order: pre-warm + warm-up, then pass 1 (the timed steps), then pass 2
         durs = []
         for f in glob.glob(out + "/kernel_trace/**/*kernel_trace.csv", recursive=True):
             for row in csv.DictReader(open(f)):
                 if "voxelize_kernel" in row["Kernel_Name"]:
                     durs.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
         durs = [d for _, d in sorted(durs)]
-        if durs:
-            timed = durs[-40:]
+        lps = max(1, len(durs) // calls_per_run) if durs else 1
+        if durs and len(durs) == lps * calls_per_run:
+            w0, t0, t1 = lps * (prewarm + warmup), lps * (prewarm + warmup), lps * (prewarm + warmup + steps)
+            timed, pass2 = durs[t0:t1], durs[-lps * steps:]
             summary["rocprof_timed_steps_avg_kernel_ns"] = sum(timed) / len(timed)
-            summary["rocprof_warmup_avg_kernel_ns"] = sum(durs[:-40]) / max(1, len(durs[:-40]))
-            lines.append(f"voxelize_kernel per-dispatch: warm-up launches avg {summary['rocprof_warmup_avg_kernel_ns']:.0f} ns, "
-                         f"timed steps (last 40) avg {summary['rocprof_timed_steps_avg_kernel_ns']:.0f} ns, min {min(timed)} max {max(timed)}")
+            summary["rocprof_pass2_avg_kernel_ns"] = sum(pass2) / len(pass2)
+            summary["rocprof_warmup_avg_kernel_ns"] = sum(durs[:w0]) / max(1, w0)
+            lines.append(f"voxelize_kernel per-dispatch: pre-warm + warm-up launches avg {summary['rocprof_warmup_avg_kernel_ns']:.0f} ns, "
+                         f"timed steps (pass 1, {len(timed)} launches) avg {summary['rocprof_timed_steps_avg_kernel_ns']:.0f} ns, min {min(timed)} max {max(timed)}; "
+                         f"pass 2 (with events) avg {summary['rocprof_pass2_avg_kernel_ns']:.0f} ns")
+        elif durs:
+            lines.append(f"voxelize_kernel: {len(durs)} dispatches, not a multiple of the {calls_per_run} steps of one run - slices not derived")
         for r in stats:
             if "voxelize_kernel" in r["Name"]:
                 summary["rocprof_avg_kernel_ns"] = float(r["AverageNs"])
-                summary["launches_per_step"] = int(r["Calls"]) // 60
-                summary["molecules_per_launch"] = batch // max(1, int(r["Calls"]) // 60)
+                summary["launches_per_step"] = max(1, int(r["Calls"]) // calls_per_run)
+                summary["molecules_per_launch"] = batch // max(1, int(r["Calls"]) // calls_per_run)
 open(out + f"/summary_{tag}.txt", "w").write("\n".join(lines) + "\n")
 json.dump(summary, open(out + "/pmc_latest.json", "w"), indent=1)
 print("\n".join(lines[:12]))

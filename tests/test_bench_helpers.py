@@ -1,8 +1,11 @@
 """bench.py pieces that do not need a GPU: the synthetic job, the cpu_baseline leg and the committed PMC summary."""
 import json
 import os
+import subprocess
+import sys
 
 import numpy as np
+import pytest
 
 import bench
 
@@ -44,3 +47,41 @@ def _check_line(line):
         assert key in line
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+
+
+def _bench(args, env_extra=None, timeout=300):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bare_bench_launches_its_own_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it starts torch.distributed.run as a child, relays rank 0's one
+    JSON line on stdout (nothing else there) and exits with the child's code. --rehearse: plumbing only, no GPU work -
+    the N = 8 form of the driver's scaling run, rehearsed where there is no 8-GPU node."""
+    res = _bench(["--gpus", str(n), "--steps", "3", "--warmup", "1", "--rehearse"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = res.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), res.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == n and rec["ranks_seen"] == n and rec["rehearsal"] is True and rec["collective_backend"] == "gloo"
+    assert rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["rank_ms_per_step"]["max"] >= rec["rank_ms_per_step"]["min"] > 0
+
+
+def test_bench_refuses_a_launcher_of_the_wrong_size():
+    res = _bench(["--gpus", "2", "--rehearse"], {"WORLD_SIZE": "3", "RANK": "0"})
+    assert res.returncode == 2 and "WORLD_SIZE=3" in res.stderr and res.stdout == ""
+
+
+def test_bare_bench_relays_the_exit_code_of_failed_ranks():
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("needs a box without a GPU: the ranks must fail")
+    res = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--batch", "1"])
+    assert res.returncode != 0 and res.stdout == ""

@@ -2,7 +2,8 @@
 
 The headline number is one forward_batch of 256 cfg-2 molecules on device tensors (gridDim.y = 256, 1.02 M atoms);
 the ligand row is cfg-4 x 128 (ragged 40-60 atoms), the stress row cfg-5 x 4. Here those very calls are checked:
-first / middle / last molecule of each batch against the CPU oracle (membership identical + the one tolerance rule),
+first / middle / last molecule of each batch against the CPU oracle (membership identical + the north-star bar as written:
+|out - ref| <= 1e-5 absolute on the full array),
 molecule 0 against the reference's golden samples, and every other molecule by property: its slice of the batch grid
 equals the same molecule's single-call grid bit for bit (what the reference's own harness asserts,
 test/test_time_numpy.py:65-69, restated for batches).
@@ -11,7 +12,7 @@ import numpy as np
 import pytest
 
 from tests import goldens
-from tests.tolerance import GAUSS_TOL, assert_gaussian
+from tests.tolerance import NORTH_STAR_ABS, assert_north_star
 
 pytestmark = pytest.mark.gpu
 
@@ -47,8 +48,10 @@ def _check_batch(mv, wl, ids, oracle_ids, single_ids):
     vox = mv.create_voxelizer(wl.resolution, wl.dimension, wl.radii_type, wl.density, library="hip", sigma=wl.sigma)
     out, d_coords, d_chan, radii, offsets = _batch_call(vox, wl, ids)
     assert not torch.isnan(out).any()
+    worst = 0.0
     for b in oracle_ids:
-        assert_gaussian(out[b].cpu().numpy(), _oracle(wl, ids[b]))
+        worst = max(worst, assert_north_star(out[b].cpu().numpy(), _oracle(wl, ids[b])))
+    print(f"{wl.name} x {len(ids)}: max |out - oracle| = {worst:.3g} (bar {NORTH_STAR_ABS:g})")
     one = vox.get_empty_grid(wl.num_channels)
     for b in single_ids:
         lo, hi = int(offsets[b]), int(offsets[b + 1])
@@ -69,7 +72,7 @@ def test_cfg2_x256_the_headline_launch():
     case = next(c for c in IDX_BIG if c["id"] == "cfg2_features_gaussian")
     flat = out[0].reshape(-1).cpu().numpy()
     idx, val = Z_BIG[f"{case['id']}/sample_idx"], Z_BIG[f"{case['id']}/sample_val"]
-    assert (np.abs(flat[idx] - val) <= GAUSS_TOL * np.maximum(1.0, np.abs(val))).all()
+    assert np.abs(flat[idx] - val).max() <= NORTH_STAR_ABS  # the reference's own values
     assert int(np.count_nonzero(flat)) == case["nonzero"]
 
 
@@ -84,7 +87,7 @@ def test_cfg4_x128_ragged_ligands():
         case = next(c for c in IDX_BIG if c["id"] == f"cfg4_features_gaussian_m{k}")
         flat = out[k].reshape(-1).cpu().numpy()
         idx, val = Z_BIG[f"{case['id']}/sample_idx"], Z_BIG[f"{case['id']}/sample_val"]
-        assert np.abs(flat[idx] - val).max() <= GAUSS_TOL
+        assert np.abs(flat[idx] - val).max() <= NORTH_STAR_ABS
         assert int(np.count_nonzero(flat)) == case["nonzero"]
 
 
@@ -98,7 +101,7 @@ def test_cfg5_x4_high_resolution():
     case = next(c for c in IDX_BIG if c["id"] == "cfg5_features_gaussian")
     flat = out[0].reshape(-1).cpu().numpy()
     idx, val = Z_BIG[f"{case['id']}/sample_idx"], Z_BIG[f"{case['id']}/sample_val"]
-    assert (np.abs(flat[idx] - val) <= GAUSS_TOL * np.maximum(1.0, np.abs(val))).all()
+    assert np.abs(flat[idx] - val).max() <= NORTH_STAR_ABS  # the reference's own values
     assert int(np.count_nonzero(flat)) == case["nonzero"]
 
 

@@ -73,6 +73,30 @@ def test_bench_py_two_rank_code_path(workload, extra):
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "rank 0 prints exactly one JSON line"
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["parity_spot"] == "ok"
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["scaling"] == "weak" and rec["parity_spot"] == "ok"
     assert rec["value"] > 0 and rec["rank_ms_per_step"]["max"] >= rec["rank_ms_per_step"]["min"] > 0
+    assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1.2
+
+
+def _bare_bench(args, timeout=900):
+    """bench.py with NO launcher and no rank variables in the environment: it must start its own ranks."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=timeout, text=True)
+
+
+@pytest.mark.parametrize("n,extra", [(2, ["--batch", "8"]), (4, ["--batch", "4"]), (4, ["--workload", "cfg4", "--ligands-per-gpu", "8"])])
+def test_bare_bench_py_starts_its_own_ranks_on_the_hip_path(n, extra):
+    """The driver's N-GPU command without the launcher (`python3 bench.py --gpus N ...`): one JSON line, every rank
+    counted, parity spot check green. On this 1-GPU box the ranks share the device (at most 4 here: the pool allows six
+    processes on a card) and rendezvous over gloo; the 8-rank form is rehearsed without GPU work in test_bench_helpers.py."""
+    res = _bare_bench(["--gpus", str(n), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"] + extra)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    lines = res.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == n and rec["ranks_seen"] == n and rec["parity_spot"] == "ok" and rec["scaling"] == "weak"
+    assert rec["collective_backend"] in ("gloo", "nccl") and rec["value"] > 0 and rec["prewarm_launches"] >= 1
     assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1.2

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from tests import goldens
-from tests.tolerance import GAUSS_TOL, P64_TOL, assert_exact, assert_gaussian
+from tests.tolerance import GAUSS_TOL, NORTH_STAR_ABS, P64_TOL, assert_exact, assert_gaussian, assert_north_star
 
 pytestmark = pytest.mark.gpu
 
@@ -79,8 +79,10 @@ def _workload(case):
 
 
 @pytest.mark.parametrize("case", IDX_BIG, ids=[c["id"] for c in IDX_BIG])
-def test_baseline_configs_golden_and_oracle(mv, case):
-    """BASELINE.json configs at full size: golden sha/samples from the reference + full-array oracle compare."""
+def test_baseline_configs_golden_and_oracle(mv, case, record_property):
+    """BASELINE.json configs at full size: golden sha/samples from the reference + full-array oracle compare.
+    Gaussian configs are held to the north-star bar as written: |out - ref| <= 1e-5 ABSOLUTE on the full array
+    (numpy/voxelizer.py:557-560 is the chain being matched), max |d| recorded as a test property."""
     from oracle import c_oracle
 
     wl = _workload(case)
@@ -95,14 +97,19 @@ def test_baseline_configs_golden_and_oracle(mv, case):
     if case["exact"]:
         assert hashlib.sha256(out.tobytes()).hexdigest() == case["sha256"]
     idx, val = Z_BIG[f"{case['id']}/sample_idx"], Z_BIG[f"{case['id']}/sample_val"]
-    assert np.abs(out.reshape(-1)[idx] - val).max() <= (0 if case["exact"] else GAUSS_TOL)
+    assert np.abs(out.reshape(-1)[idx] - val).max() <= (0 if case["exact"] else GAUSS_TOL)  # the reference's own values
     sums = out.reshape(out.shape[0], -1).sum(axis=1, dtype=np.float64)
     assert np.allclose(sums, Z_BIG[f"{case['id']}/chan_sums"], rtol=2e-6, atol=1e-3)
     # full-array comparison with the CPU oracle (itself pinned to the reference by test_oracle_golden.py)
     xyz = wl.coords[i] - wl.centers[i].reshape(1, 3)
     ora = c_oracle.voxelize(xyz, chan, wl.radii[i], resolution=wl.resolution, dimension=wl.dimension,
                             radii_type=wl.radii_type, density=density, sigma=wl.sigma, num_channels=out.shape[0])
-    _compare(out, ora, exact=case["exact"])
+    if case["exact"]:
+        assert_exact(out, ora)
+    else:
+        worst = assert_north_star(out, ora)
+        record_property("max_abs_err", worst)
+        print(f"{case['id']}: max |out - oracle| = {worst:.3g} (bar {NORTH_STAR_ABS:g}), max value {float(ora.max()):.3g}")
 
 
 @pytest.mark.parametrize("case", IDX_DENSE, ids=[c["id"] for c in IDX_DENSE])
@@ -866,6 +873,32 @@ def test_overlapped_prepass_equals_serial_calls(mv):
         one = fast.forward_features(dev[0][0][:700], None, dev[0][1][:700], dev[0][3] if radii_type != "atom-wise" else dev[0][3][:700])
         assert torch.equal(one, want[0][0])
         assert torch.equal(fast.forward_batch(dev[1][0], dev[1][2], None, dev[1][1], dev[1][3], num_channels=dev[1][4]), want[1])
+
+
+def test_per_molecule_calls_with_overlap_enabled_wait_for_their_converted_inputs(mv):
+    """overlap_prepass concerns batched calls only (mvx.h: "the batched three-launch path"). A per-molecule forward() on
+    such a handle - binned route (a cfg-5-sized molecule), float32 device coords and a float32 device centre that this
+    layer converts to float64 ON the caller's stream right before the call - must not read them from a side stream that
+    never waited: same grid as a serial handle, call after call, with no synchronisation in between."""
+    import torch
+
+    rng = np.random.default_rng(321)
+    D, N, C_ = 96, 9000, 8
+    W_ = 0.5 * (D - 1)
+    serial = mv.create_voxelizer(0.5, D, "atom-wise", "gaussian", "hip", sigma=0.7)
+    fast = mv.create_voxelizer(0.5, D, "atom-wise", "gaussian", "hip", sigma=0.7, overlap_prepass=True)
+    for v in (serial, fast):
+        v.debug_option("direct", 0)
+    for rep in range(4):
+        xyz32 = torch.as_tensor(rng.uniform(-W_ / 2, W_ / 2, (N, 3)) + 3.0, dtype=torch.float32, device="cuda")
+        cen32 = torch.full((3,), 3.0, dtype=torch.float32, device="cuda")
+        feat64 = torch.as_tensor(rng.random((N, C_)), dtype=torch.float64, device="cuda")  # converted to float32 by the layer
+        rad64 = torch.as_tensor(rng.uniform(0.8, 1.9, N), dtype=torch.float64, device="cuda")
+        got = fast.forward(xyz32, cen32, feat64, rad64)
+        want = serial.forward(xyz32, cen32, feat64, rad64)
+        assert torch.equal(got, want), rep
+        ty = torch.as_tensor(rng.integers(0, 5, N), dtype=torch.int64, device="cuda")  # int32 copy made by the layer
+        assert torch.equal(fast.forward(xyz32, cen32, ty, rad64), serial.forward(xyz32, cen32, ty, rad64)), rep
 
 
 def test_per_molecule_fast_path_replayed_with_changing_arguments(mv):
