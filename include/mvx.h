@@ -215,7 +215,7 @@ int mvx_debug_read_records(mvx_handle *h, void *host_dst, int64_t n, void *strea
  *   "max_ct64" = 16 | 32: float64 grids: channels one workgroup accumulates (default 32: Gaussian grids of more than
  *              16 channels take 32 per workgroup on 4-wave slabs; 16 = the two-chunk form every other grid uses);
  *   "nw" = 1..16: waves (8-voxel z sub-tiles) per slab instead of the plan's (0 = the plan); measurement aid;
- *   "dense_grid" = k: workgroups of the voxelize_dense_kernel launch (0 = 512); measurement aid. */
+ *   "dense_grid": accepted and ignored (round 2's second voxelize launch no longer exists). */
 int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value);
 #ifdef __cplusplus
 }

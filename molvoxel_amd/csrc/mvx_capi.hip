@@ -65,7 +65,7 @@ constexpr long long DIRECT_MAX_ATOM_TESTS = 16ll << 20;
 // mvx_set_overlap, the pre-pass of call k+1 can fill one set on the side stream while call k's voxelize launches
 // still read the other.
 struct Workspace {
-    DevBuf rec, wbuf, xp, xlist, slist, overflow, meta, aux;
+    DevBuf rec, wbuf, xp, xlist, slist, meta, aux;
     std::vector<char> meta_last; // host copy of the offsets the device meta buffer holds
     bool meta_valid = false;
     hipEvent_t ev_pre = nullptr; // pre-pass into this set finished (side stream)
@@ -88,7 +88,6 @@ struct mvx_handle {
     int ev_count = 0;           // timed launches recorded since the last read
     bool profiling = false;
     int force_nw = 0;
-    int dense_grid = 0;
     int max_ct64 = 32; // channels per workgroup on float64 grids (debug option "max_ct64": 16 = two chunks for C = 32)
     int max_ct = 32;
     // Pipelined pre-pass (MVX_PIPELINE=k, k > 1): the batch is cut into k chunks of molecules; prep + binning of chunk
@@ -492,7 +491,6 @@ int run(mvx_handle *h, const RunArgs &r) {
         // x-lists: packed regions, (sum(N) + 2*B) * nsx entries; slab lines: primary + extension entries per slab
         if ((rc = ensure(w.xlist, ((size_t)total + 2 * (size_t)r.B) * sp.nsx * sizeof(uint2)))) return rc;
         if ((rc = ensure(w.slist, nslabs * (SLAB_LINE_ENTRIES + SLAB_EXT_ENTRIES) * sizeof(uint2)))) return rc;
-        if ((rc = ensure(w.overflow, (nslabs * (size_t)ncc + 1) * sizeof(int)))) return rc;
     }
     uint2 *d_xlist = reinterpret_cast<uint2 *>(w.xlist.p);
     uint2 *d_slist = reinterpret_cast<uint2 *>(w.slist.p);
@@ -562,8 +560,6 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.Tc = d_Tc;
     va.kc = d_kc;
     va.out = d_out;
-    va.overflow = reinterpret_cast<int *>(w.overflow.p);
-    va.dense_grid = (unsigned)h->dense_grid;
     va.p.res = g.res;
     va.p.half = g.half;
     va.p.D = D;
@@ -645,9 +641,8 @@ int run(mvx_handle *h, const RunArgs &r) {
         pa.first = r.offsets[b0];
         pa.total = r.offsets[b1];
         HIP_TRY(launch_prep(pa, pre));
-        // (the first launch also zeroes the overflow counter)
         HIP_TRY(launch_xbin(pa.xp, in.offsets, total, b0, b1 - b0, max_atoms, sp.nsx, sp.nsy, sp.nzc, sp.NW, d_xlist, d_slist,
-                            d_slist_ext, k == 0 ? va.overflow : nullptr, pre));
+                            d_slist_ext, pre));
         if (side_stream) HIP_TRY(hipEventRecord(overlap ? w.ev_pre : h->ev_pre[k], pre));
         return MVX_OK;
     };
@@ -666,9 +661,6 @@ int run(mvx_handle *h, const RunArgs &r) {
             // the bracket holds voxelize_kernel alone (what rocprofv3 reports under that name)
             if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, ct, gauss, chanwise, lane_range, s); }))) return rc;
         }
-        // a slab is left to the dense kernel only beyond line + extension (255 candidates): impossible when no molecule
-        // has that many atoms
-        if (max_atoms > SLAB_LINE_ENTRIES + SLAB_EXT_ENTRIES - 1) HIP_TRY(launch_voxelize_dense(va, ct, gauss, chanwise, lane_range, s));
     }
 
     if (overlap) { // the next call but one refills this set
@@ -755,7 +747,7 @@ int mvx_destroy(mvx_handle *h) {
     (void)hipDeviceSynchronize();
     std::vector<DevBuf *> bufs = {&h->xf_buf, &h->in_coords, &h->in_chan, &h->in_radii, &h->out_stage};
     for (Workspace &w : h->ws) {
-        for (DevBuf *b : {&w.rec, &w.wbuf, &w.xp, &w.xlist, &w.slist, &w.overflow, &w.meta, &w.aux}) bufs.push_back(b);
+        for (DevBuf *b : {&w.rec, &w.wbuf, &w.xp, &w.xlist, &w.slist, &w.meta, &w.aux}) bufs.push_back(b);
         if (w.ev_pre) (void)hipEventDestroy(w.ev_pre);
         if (w.ev_vox) (void)hipEventDestroy(w.ev_vox);
     }
@@ -938,7 +930,7 @@ int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
     else if (n == "max_ct") h->max_ct = std::max(1, std::min(32, (int)value));
     else if (n == "direct") h->direct_mode = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "max_ct64") h->max_ct64 = value >= 32 ? 32 : 16;
-    else if (n == "dense_grid") h->dense_grid = value > 0 ? value : 0;
+    else if (n == "dense_grid") (void)value; // (accepted and ignored: there is no second voxelize launch any more)
     else if (n == "nw") h->force_nw = (value >= 1 && value <= 16) ? value : 0; // waves (8-voxel z sub-tiles) per slab; 0 = the default plan
     else if (n == "mall_budget_kb") h->mall_budget = value > 0 ? 1024.0 * (double)value : MALL_BUDGET;
 #ifdef MVX_DIAG

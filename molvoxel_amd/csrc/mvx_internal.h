@@ -112,8 +112,6 @@ struct VoxArgs {
     const double *Tc;      // channel-wise features: per-channel d2 thresholds (float64 grids: the radii themselves)
     const float *kc;       //                        per-channel gaussian coefficients
     void *out;             // (B, C, D, D, D) float, or double for float64 grids
-    int *overflow;         // [0] = count (zeroed per call), [1..] ids of the slabs left to voxelize_dense_kernel
-    unsigned dense_grid;   // workgroups of the voxelize_dense_kernel launch (they loop over the list)
     VoxParams p;
 };
 
@@ -124,17 +122,15 @@ hipError_t launch_chan_aux64(const double *radii, int32_t C, int32_t density, do
                              hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
 hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, int32_t b0, int32_t nb, int64_t max_atoms, int32_t nsx, int32_t nsy,
-                       int32_t nzc, int32_t NW, uint2 *xlist, uint2 *slist, uint2 *slist_ext, int *zero_counter, hipStream_t s);
+                       int32_t nzc, int32_t NW, uint2 *xlist, uint2 *slist, uint2 *slist_ext, hipStream_t s);
 constexpr int SLAB_LINE_ENTRIES = 64;  // = SLOTS in mvx_kernels.hip
 constexpr int SLAB_EXT_ENTRIES = 192;  // = EXT_SLOTS
 hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf_dev, double *out, hipStream_t s);
 // ct: channels per thread (1, 4, 8, 16, 32); lane_range: per-lane index-range check needed
-// voxelize molecules [a.p.b0, a.p.b0 + nb); slabs with more candidates than one line go to the overflow list
+// voxelize molecules [a.p.b0, a.p.b0 + nb): every slab, whatever its candidate count (line, line + extension, x-list)
 hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
 // float64 grids: every slab of the whole batch through the general slab loop (ct <= 16; a.p.dcap must be 64)
 hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
-// process the overflow list of all launches since it was zeroed (one launch per call)
-hipError_t launch_voxelize_dense(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
 // the whole call in one launch (float32 grids, NW <= 8): no workspace, no pre-pass
 hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, bool chanwise,
                                   bool lane_range, hipStream_t s);

@@ -555,7 +555,7 @@ static_assert(SLOTS == SLAB_LINE_ENTRIES && EXT_SLOTS == SLAB_EXT_ENTRIES, "slab
 template <int THREADS, int XLN, int CH, int NQ>
 __global__ void __launch_bounds__(THREADS)
     xbin_kernel(const uint2 *__restrict__ xp, const int64_t *__restrict__ offsets, int64_t n_one, int b0, int nsx, int nsy, int nzc, int NW,
-                uint2 *__restrict__ xlist, uint2 *__restrict__ slist, uint2 *__restrict__ slist_ext, int *zero_counter) {
+                uint2 *__restrict__ xlist, uint2 *__restrict__ slist, uint2 *__restrict__ slist_ext) {
     __shared__ uint2 xs[XLN]; // (one-wave blocks serve molecules of <= 256 atoms: XLN = 256)
     constexpr int NWV = THREADS / 64; // waves per block
     __shared__ int wcnt[2][NWV];
@@ -565,7 +565,6 @@ __global__ void __launch_bounds__(THREADS)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t a0 = offsets ? offsets[b] : 0, a1 = offsets ? offsets[b + 1] : n_one; // (null: one molecule of n_one atoms)
     const int x0 = SUBX * sx;
-    if (zero_counter && blockIdx.x == 0 && tid == 0) *zero_counter = 0; // overflow list of the voxelize launches
     if (tid == 0) any_overflow = 0;
     uint2 *dst = xlist + ((size_t)a0 + 2 * (size_t)b) * nsx + (size_t)sx * (size_t)(a1 - a0 + XL_HEADER);
     int count = 0, phase = 0;
@@ -726,7 +725,14 @@ __global__ void __launch_bounds__(THREADS)
             const unsigned hdr = (n[q] > LINE_CAP) ? LINE_OVERFLOW : (unsigned)n[q];
             if (lane == 0) {
                 ln[q * SLOTS] = make_uint2(hdr, (unsigned)a0);
-                if (n[q] > LINE_CAP) any_overflow = 1;
+                if (n[q] > LINE_CAP) {
+                    any_overflow = 1;
+                    // an overflowing slab's line carries, in entry 1, where its (molecule, x-slab) list lives: the voxelize
+                    // kernel then needs no list base, no offsets and no atom count for this rare path (kernel arguments
+                    // it would hold in scalar registers through its whole hot path)
+                    const unsigned long long at = (unsigned long long)reinterpret_cast<uintptr_t>(dst);
+                    ln[q * SLOTS + 1] = make_uint2((unsigned)at, (unsigned)(at >> 32));
+                }
             }
             // the primary line leaves as one store of the used part, rounded up to 32 B (entries past the count are
             // never interpreted): an empty slab costs 32 B, not 512. (nt stores: the line then misses L2 in the
@@ -750,14 +756,14 @@ __global__ void __launch_bounds__(THREADS)
 }
 
 hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, int32_t b0, int32_t nb, int64_t max_atoms, int32_t nsx, int32_t nsy,
-                       int32_t nzc, int32_t NW, uint2 *xlist, uint2 *slist, uint2 *slist_ext, int *zero_counter, hipStream_t s) {
+                       int32_t nzc, int32_t NW, uint2 *xlist, uint2 *slist, uint2 *slist_ext, hipStream_t s) {
     if (nb <= 0) return hipSuccess;
     const int nslab = nsy * nzc;
     if (max_atoms <= 256) { // small molecules (one round of pass A for a single wave): one-wave blocks
         int parts = 1;
         while (parts * 4 < nslab && parts < 4 && (long long)nb * nsx * parts < 8192) parts *= 2;
         hipLaunchKernelGGL((xbin_kernel<64, 256, 4, 4>), dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(64), 0, s, xp, offsets, n_one, b0, nsx,
-                           nsy, nzc, NW, xlist, slist, slist_ext, zero_counter);
+                           nsy, nzc, NW, xlist, slist, slist_ext);
         return hipGetLastError();
     }
     // one block builds 16 slab lines per pass; grids with more slabs per x-slab (D > 64) and few molecules get
@@ -778,10 +784,10 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
     do {                                                                                                                              \
         if (four)                                                                                                                     \
             hipLaunchKernelGGL((xbin_kernel<1024, 2 * XL_LDS, CHUNKS, 4>), grid, dim3(1024), 0, s, xp, offsets, n_one, b0, nsx, nsy, nzc, \
-                               NW, xlist, slist, slist_ext, zero_counter);                                                            \
+                               NW, xlist, slist, slist_ext);                                                                          \
         else                                                                                                                          \
             hipLaunchKernelGGL((xbin_kernel<1024, 4 * XL_LDS, CHUNKS, 1>), grid, dim3(1024), 0, s, xp, offsets, n_one, b0, nsx, nsy, nzc, \
-                               NW, xlist, slist, slist_ext, zero_counter);                                                            \
+                               NW, xlist, slist, slist_ext);                                                                          \
     } while (0)
             if (max_atoms <= 4 * 1024) MVX_XBIN_BIG(4); // all of the largest molecule's atoms in flight at once when <= 16 384
             else if (max_atoms <= 6 * 1024) MVX_XBIN_BIG(6);
@@ -798,7 +804,7 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
     const dim3 grid((unsigned)(nb * nsx), (unsigned)parts);
 #define MVX_XBIN_256(CHUNKS)                                                                                                          \
     hipLaunchKernelGGL((xbin_kernel<256, XL_LDS, CHUNKS, 4>), grid, dim3(256), 0, s, xp, offsets, n_one, b0, nsx, nsy, nzc, NW, xlist, \
-                       slist, slist_ext, zero_counter)
+                       slist, slist_ext)
     if (max_atoms <= 1024) MVX_XBIN_256(4);
     else if (max_atoms <= 2048) MVX_XBIN_256(8);
     else MVX_XBIN_256(16);
@@ -857,7 +863,16 @@ __device__ __forceinline__ void store_f4(float *dst, const float4 v, int kind) {
 
 // floats per tile row: SUBZ*NW plus a pad that keeps ds_write_b32 conflict-free for the lane -> (row, column) map
 __host__ __device__ __forceinline__ int row_stride_floats(int NW) { return SUBZ * NW + 8; }
-__host__ __device__ __forceinline__ int cand_stride_words(int ct) { return 16 + (ct < 4 ? 4 : ct); }
+// words per staged row: 16 of record + the channel weights, padded to an ODD number of 16-B quads - the row filter reads one
+// row per lane (ds_read_b128 at a lane stride of one row): with 12 quads per row (CT = 32) sixteen lanes fell on four
+// distinct bank groups (4-way conflict, and 16-way for the 4-byte read of the z range); with 13 they are conflict-free
+__host__ __device__ constexpr int cand_stride_words(int ct) {
+    const int w = 16 + (ct < 4 ? 4 : ct);
+#ifdef MVX_SW_PLAIN // (A/B builds)
+    return w;
+#endif
+    return ((w / 4) & 1) ? w : w + 4;
+}
 
 #ifndef MVX_CR
 #define MVX_CR 4 // channels per transposition round of the float32 write-out: 512 threads read back exactly one 32-row tile
@@ -903,6 +918,7 @@ size_t dense64_lds_bytes(int32_t ct, int32_t NW) {
 // what a lane knows about its voxel and its workgroup's slab
 struct LaneCtx {
     double gx, gy, gz; // voxel centre: axis[i] = i*res - width/2 (numpy/voxelizer.py:41-43)
+    double gx1;        // OpsMx32 only (two voxels per lane: (ix, iy, iz) and (ix + 1, iy, iz)): the second voxel's x
     int ix, iy, iz;
     int zt_w;          // this wave's sub-tile index along z
     int cbase;         // first channel of this workgroup's chunk
@@ -914,7 +930,9 @@ __device__ __forceinline__ void accumulate_row(float2v (&acc)[(CT + 1) / 2], con
                                                const double *__restrict__ Tc, const float *__restrict__ kc) {
     const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
     const double2 PzT = *reinterpret_cast<const double2 *>(r + 4); // pz, T
-    const uint4 q = *reinterpret_cast<const uint4 *>(r + 8);       // k, type, xr, yr
+    uint4 q;                                                       // k, type, xr, yr
+    if (LANE_RANGE) q = *reinterpret_cast<const uint4 *>(r + 8);
+    else q.x = r[8]; // (k alone: a 4-byte broadcast read is half the LDS cycles of a 16-byte one)
     const double dx = Pxy.x - L.gx, dy = Pxy.y - L.gy, dz = PzT.x - L.gz;
     const double d2 = (dx * dx + dy * dy) + dz * dz; // cdist order, no fma
     bool hit = d2 <= PzT.y;
@@ -1163,7 +1181,7 @@ struct OpsF32 {
     typedef float2v Acc[(CT + 1) / 2];
     static constexpr int WORDS = 1;                   // 32-bit words per channel weight
     static constexpr int WW = CT;                     // weight words staged per row
-    static constexpr int SW = 16 + (CT < 4 ? 4 : CT); // row stride in LDS, words
+    static constexpr int SW = cand_stride_words(CT);  // row stride in LDS, words
     static __device__ __forceinline__ void zero(Acc &acc) {
 #pragma unroll
         for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
@@ -1171,6 +1189,18 @@ struct OpsF32 {
     static __device__ __forceinline__ void accumulate(Acc &acc, const unsigned *r, const LaneCtx &L, const VoxParams &P,
                                                       const double *__restrict__ Tc, const float *__restrict__ kc) {
         accumulate_row<CT, GAUSS, CHANWISE, LANE_RANGE>(acc, r, L, P.C, Tc, kc);
+    }
+    static __device__ __forceinline__ LaneCtx ctx(int lane, int wave, int x0, int y0, int z0, int zt_lo, int cbase, const VoxParams &P) {
+        return make_lane_ctx(lane, wave, x0, y0, z0, zt_lo, cbase, P);
+    }
+    // the rows of `mask` (one bit per staged row, atom order) into the accumulators
+    static __device__ __forceinline__ void walk(Acc &acc, unsigned long long mask, const unsigned *un, int lane, const LaneCtx &L,
+                                                const VoxParams &P, const double *__restrict__ Tc, const float *__restrict__ kc) {
+        while (mask) {
+            const int sl = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            accumulate(acc, un + sl * SW, L, P, Tc, kc);
+        }
     }
     static __device__ __forceinline__ void write(const Acc &acc, bool any, unsigned *un, int tid, int lane, int wave, int NW,
                                                  int b, const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
@@ -1184,6 +1214,155 @@ struct OpsF32 {
                                                       int b, const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
         write_slab<CT, DIRECT_CR>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
                                   static_cast<float *>(out), P);
+    }
+};
+
+// ---- 32 channels on the matrix cores ---------------------------------------------------------------------------------
+// What a wave does per candidate is a rank-1 update of its (32 channels x 64 voxels) tile: acc[c][v] += w[c] * val[v] -
+// the reference's own formulation is a matmul (numpy/voxelizer.py:232-235). On the vector ALU that costs, per candidate
+// and wave, 16 v_pk_fma_f32 (64 issue cycles) and eight 16-B LDS broadcast reads of the weight row (32 LDS cycles: a
+// ds_read_b128 takes 4 cycles whether or not its 64 lanes read the same address), and these two are what bounds the
+// kernel once slabs hold more than ~60 candidates (radii >= 1.5 A on a 0.5 A grid; rocprofv3 counters in
+// profiles/r03_radius_pmc.txt: LDS array 66 % and vector ALU 62 % busy at 2.0 A, 0.41 of the HBM peak).
+// v_mfma_f32_32x32x2_f32 does the same update for TWO candidates in float32 - D = fma(a1, b1, fma(a0, b0, C)), one
+// rounding per step, k = 0 first (probed on the hardware: tools/micro/mfma_layout.hip), i.e. bit for bit the chain of
+// fmaf in candidate order that the vector path evaluates - on the matrix pipe, which runs beside the vector ALU, and it
+// takes its operands one dword per lane: A[i = lane % 32][k = lane / 32], B[k = lane / 32][j = lane % 32]. With
+// A = weights (i = channel) and B = values (j = voxel):
+//   * lane l evaluates candidate k = l / 32 of the pair for TWO voxels, (x0, ly, lz) and (x0 + 1, ly, lz) with
+//     (ly, lz) = ((l % 32) / 8, l % 8): the same fp64 d2 / threshold / exp2 work per (voxel, candidate) as before
+//     (dy^2 and dz^2 are shared by the two voxels), two MFMAs per pair (x plane and x + 1 plane);
+//   * the weight operand is ONE 4-byte LDS read per pair (lane l: weight l % 32 of its candidate's row) instead of
+//     sixteen 16-byte broadcast reads: LDS cycles per candidate 44 -> 6.
+// D[i][j] comes out with lane l holding voxel j = l % 32 - the (ly, lz) it evaluated - for the channels
+// i = (r % 4) + 8 (r / 4) + 4 (l / 32), r = 0..15: one voxel per lane as in the vector path, half the channels in each half
+// of the wave. The write-out therefore keeps the vector path's tile ([channel][x, y row][z], eight channels per round
+// here: channels 8m .. 8m+3 sit in registers 4m .. 4m+3 of lanes 0-31, channels 8m+4 .. 8m+7 in the same registers of
+// lanes 32-63, so every lane writes 4 channels x 2 planes per round) and its read-back / store code unchanged.
+typedef float f16v __attribute__((ext_vector_type(16)));
+constexpr int MX_CR = 8; // channels per write-out round of the matrix-core path
+size_t voxelize_mx_lds_bytes(int32_t NW) { return voxelize_lds_bytes(32, NW, MX_CR); }
+
+template <bool GAUSS, bool LANE_RANGE>
+struct OpsMx32 {
+    static constexpr int CT = 32;
+    struct Acc {
+        f16v p0, p1; // the x0 plane and the x0 + 1 plane of the sub-tile
+    };
+    static constexpr int WORDS = 1;
+    static constexpr int WW = 32;
+    static constexpr int SW = cand_stride_words(32);
+    static __device__ __forceinline__ void zero(Acc &acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc.p0[r] = acc.p1[r] = 0.0f;
+    }
+    static __device__ __forceinline__ LaneCtx ctx(int lane, int wave, int x0, int y0, int z0, int zt_lo, int cbase, const VoxParams &P) {
+        const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1);
+        LaneCtx L;
+        L.ix = x0; // (x0 is a multiple of SUBX)
+        L.iy = y0 + ly;
+        L.iz = z0 + SUBZ * wave + lz;
+        L.gx = (double)L.ix * P.res - P.half;
+        L.gx1 = (double)(L.ix + 1) * P.res - P.half;
+        L.gy = (double)L.iy * P.res - P.half;
+        L.gz = (double)L.iz * P.res - P.half;
+        L.zt_w = zt_lo + wave;
+        L.cbase = cbase;
+        return L;
+    }
+    static __device__ __forceinline__ void walk(Acc &acc, unsigned long long mask, const unsigned *un, int lane, const LaneCtx &L,
+                                                const VoxParams &P, const double *__restrict__, const float *__restrict__) {
+        const bool upper = lane >= 32; // this lane evaluates the pair's second candidate
+        const int j = lane & 31;       // ... and feeds the weight of channel j of that candidate's row
+        while (mask) {
+            const int s0 = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const bool two = mask != 0; // (uniform)
+            int s1 = s0;
+            if (two) {
+                s1 = __builtin_ctzll(mask);
+                mask &= mask - 1;
+            }
+            const bool valid = !upper || two; // an odd row count: the last pair's second half adds fma(0, 0, acc) = acc
+            const unsigned *r = un + (upper ? s1 : s0) * SW;
+            const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
+            const double2 PzT = *reinterpret_cast<const double2 *>(r + 4); // pz, T
+            const double dx0 = Pxy.x - L.gx, dx1 = Pxy.x - L.gx1, dy = Pxy.y - L.gy, dz = PzT.x - L.gz;
+            const double dy2 = dy * dy, dz2 = dz * dz;
+            const double d2a = (dx0 * dx0 + dy2) + dz2; // cdist order, no fma
+            const double d2b = (dx1 * dx1 + dy2) + dz2;
+            bool hita = valid && d2a <= PzT.y, hitb = valid && d2b <= PzT.y;
+            float k;
+            if (LANE_RANGE) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(r + 8); // k, type, xr, yr
+                const unsigned zr = r[12];
+                k = __uint_as_float(q.x);
+                const bool yz = (L.iy >= (int)(q.w & 0xffff)) && (L.iy <= (int)(q.w >> 16)) && (L.iz >= (int)(zr & 0xffff)) &&
+                                (L.iz <= (int)(zr >> 16));
+                hita = hita && yz && (L.ix >= (int)(q.z & 0xffff)) && (L.ix <= (int)(q.z >> 16));
+                hitb = hitb && yz && (L.ix + 1 >= (int)(q.z & 0xffff)) && (L.ix + 1 <= (int)(q.z >> 16));
+            } else {
+                k = __uint_as_float(r[8]);
+            }
+            const float eva = GAUSS ? __builtin_amdgcn_exp2f(k * (float)d2a) : 1.0f;
+            const float evb = GAUSS ? __builtin_amdgcn_exp2f(k * (float)d2b) : 1.0f;
+            const float va = hita ? eva : 0.0f, vb = hitb ? evb : 0.0f;
+            const float wj = valid ? __uint_as_float(r[16 + j]) : 0.0f;
+            acc.p0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wj, va, acc.p0, 0, 0, 0);
+            acc.p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wj, vb, acc.p1, 0, 0, 0);
+        }
+    }
+    static __device__ __forceinline__ void write(const Acc &acc, bool any, unsigned *un, int tid, int lane, int wave, int NW,
+                                                 int b, const LaneCtx &L, int x0, int y0, int z0, void *out_, const VoxParams &P) {
+        float *out = static_cast<float *>(out_);
+        if (!any) { // zero fill without the LDS round trip: the one-voxel-per-lane code (no accumulator is read)
+            float2v zero[16];
+            write_slab<32>(zero, false, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0, out, P);
+            return;
+        }
+        float *tile = reinterpret_cast<float *>(un);
+        constexpr int CR = MX_CR, NROUND = 32 / CR;
+        const int D = P.D;
+        const int RS = row_stride_floats(NW);
+        const size_t D2 = (size_t)D * D, D3 = D2 * D;
+        // read-back exactly as write_slab: thread t takes float4 slot q of row rfirst (+ 4 channels per pass)
+        const int F4 = (SUBZ / 4) * NW;
+        const int q = tid % F4, rfirst = tid / F4, zq = z0 + 4 * q;
+        const int sxx = (rfirst >> SUBY_SH) & (SUBX - 1), syy = rfirst & (SUBY - 1), cfirst = rfirst / RPC;
+        const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
+        float *dst0 = out + ((size_t)b * P.C + L.cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
+        // this lane's voxel column in the tile, and the first of its four channels of a round
+        const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1), h = lane >> 5;
+        float *mine = tile + (4 * h * RPC + ly) * RS + SUBZ * wave + lz; // + (c * RPC + x * SUBY) * RS
+#pragma unroll
+        for (int rd = 0; rd < NROUND; ++rd) {
+            __syncthreads(); // candidate rows (round 0) / previous tile (later rounds) fully consumed
+            if (rd == 0) VK_STAMP(4); // every wave's walk is done
+            if (rd == 1) VK_STAMP(5); // round 0 transposed and its stores issued
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                mine[(c * RPC) * RS] = acc.p0[4 * rd + c];
+                mine[(c * RPC + SUBY) * RS] = acc.p1[4 * rd + c];
+            }
+            __syncthreads();
+            if (vox_ok) {
+#pragma unroll
+                for (int p = 0; p < (CR + 3) / 4; ++p) {
+                    const int c = cfirst + 4 * p; // channel inside the round
+                    if (c < CR && L.cbase + rd * CR + c < P.C) {
+                        const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 4 * RPC * p) * RS + 4 * q);
+                        float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
+                        if (P.vec_store) {
+                            store_f4(dst, v, P.store_kind);
+                        } else {
+                            const float e4[4] = {v.x, v.y, v.z, v.w};
+                            for (int k = 0; k < 4; ++k)
+                                if (zq + k < D) dst[k] = e4[k];
+                        }
+                    }
+                }
+            }
+        }
     }
 };
 
@@ -1260,14 +1439,48 @@ __device__ __forceinline__ void line_round(typename Ops::Acc &acc, const uint2 E
     VK_STAMP(8 + wave); // every wave's own walk end
 }
 
+// Can the atom of staged row r reach ANY voxel centre of this wave's sub-tile? The candidate lists are built from index
+// ranges, i.e. from the atom's bounding box: of the rows whose box meets the sub-tile's box, 15 % (radius 1 A on the 0.5 A
+// grid) to 27 % (2 A) come no closer than their radius to its nearest corner, and a walked candidate costs ~116 vector
+// and 44 LDS cycles whether or not a lane hits. One lane per row: distance from the atom to the box spanned by the
+// sub-tile's voxel centres (centre / half-extent form, float32) against the membership threshold T. This only drops
+// rows; the estimate is made a lower bound of the true distance (below), and everything it keeps is decided per voxel by
+// the exact d2 <= T as before.
+// Coordinates float32 cannot hold (huge or non-finite: test_non_finite_...) compare false and keep the row.
+__device__ __forceinline__ bool reaches_subtile(const unsigned *r, int lane, const LaneCtx &L, const VoxParams &P) {
+    const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
+    const double2 PzT = *reinterpret_cast<const double2 *>(r + 4); // pz, T
+    const float res = (float)P.res;
+    // this lane's voxel is (lx, ly, lz) inside the sub-tile: the box centre is the same for every lane
+    // (lx: lanes 32..63 hold the x + 1 plane in the one-voxel-per-lane layout; in the two-voxel layout every lane's gx is
+    // the x plane's and the upper half of the wave holds other candidates, not other voxels: L.ix tells which)
+    const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1), lx = L.ix & (SUBX - 1);
+    const float cx = (float)L.gx + (0.5f * (SUBX - 1) - (float)lx) * res;
+    const float cy = (float)L.gy + (0.5f * (SUBY - 1) - (float)ly) * res;
+    const float cz = (float)L.gz + (0.5f * (SUBZ - 1) - (float)lz) * res;
+    // every axis distance is shortened by 2e-6 of the magnitudes it was formed from (each float32 conversion and
+    // operation is off by at most 6e-8 of them): the estimate never exceeds the true distance, at any grid scale
+    const float px = (float)Pxy.x, py = (float)Pxy.y, pz = (float)PzT.x;
+    const float hx = 0.5f * (SUBX - 1) * res, hy = 0.5f * (SUBY - 1) * res, hz = 0.5f * (SUBZ - 1) * res;
+    const float ex = fmaxf(fabsf(px - cx) - hx - 2.0e-6f * (fabsf(px) + fabsf(cx) + hx), 0.0f);
+    const float ey = fmaxf(fabsf(py - cy) - hy - 2.0e-6f * (fabsf(py) + fabsf(cy) + hy), 0.0f);
+    const float ez = fmaxf(fabsf(pz - cz) - hz - 2.0e-6f * (fabsf(pz) + fabsf(cz) + hz), 0.0f);
+    const float dmin2 = ex * ex + ey * ey + ez * ez;
+    const float T = (float)PzT.y;
+    return !(dmin2 > T * 1.00001f);
+}
+
 // The same round for voxelize_kernel, with the line read through the SCALAR memory path: the header and the atom
 // indices of the (at most eight) slots this wave stages are wave-uniform, so they are s_load'ed (scalar cache -> L2)
 // instead of travelling, 512 B per wave, through the vector memory pipeline - where a load queues behind the 64 KB of
 // stores every resident workgroup pushes through the same pipeline (the line load took 3 000 cycles at the median,
 // profiles/r02_phase_timelines.txt). The z sub-tile filter reads the admitted z range from the staged records instead
 // of the line's packed copy (same bits: both come from prep_atom's range, in SUBZ-voxel units).
+// xl (workgroup-uniform, rare): the entries come from a (molecule, x-slab) list instead of a slab line (LINE_OVERFLOW slabs,
+// below): they have not been filtered against the slab's y rows, so the walk's row filter also tests the record's admitted
+// y range.
 template <typename Ops>
-__device__ __forceinline__ void line_round_scalar(typename Ops::Acc &acc, const uint2 *__restrict__ line, const uint2 *__restrict__ ext,
+__device__ __forceinline__ void line_round_scalar(const bool xl, typename Ops::Acc &acc, const uint2 *__restrict__ line, const uint2 *__restrict__ ext,
                                                   int e0, int n_line, int RW, unsigned *un, const unsigned *__restrict__ rec,
                                                   const unsigned *__restrict__ w, int64_t a0, int lane, int wave, int NW, const LaneCtx &L,
                                                   const VoxParams &P, const double *__restrict__ Tc, const float *__restrict__ kc) {
@@ -1300,24 +1513,40 @@ __device__ __forceinline__ void line_round_scalar(typename Ops::Acc &acc, const 
     VK_STAMP(3);
     bool ok = false;
     if (lane < RW && e0 + lane >= 1 && e0 + lane <= n_line) {
-        const unsigned zr = un[lane * SW + 12];
+        const unsigned *r = un + lane * SW;
+        const unsigned zr = r[12];
         ok = ((int)((zr & 0xffff) >> SUBZ_SH) <= L.zt_w) && ((int)((zr >> 16) >> SUBZ_SH) >= L.zt_w);
+#ifndef MVX_NO_CULL // (A/B builds)
+        ok = ok && reaches_subtile(r, lane, L, P);
+#endif
+        if (xl) {
+            const unsigned yr = r[11];
+            const int sy = L.iy >> SUBY_SH; // (the slab's y index: the same for every lane)
+            ok = ok && ((int)((yr & 0xffff) >> SUBY_SH) <= sy) && ((int)((yr >> 16) >> SUBY_SH) >= sy);
+        }
     }
-    unsigned long long mask = __ballot(ok);
-    while (mask) {
-        const int sl = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        Ops::accumulate(acc, un + sl * SW, L, P, Tc, kc);
-    }
+    Ops::walk(acc, __ballot(ok), un, lane, L, P, Tc, kc);
     VK_STAMP(8 + wave); // every wave's own walk end
 }
+
+// voxelize_kernel's arithmetic: 32-channel chunks go to the matrix cores (OpsMx32), everything else to the vector ALU
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+struct SlabOps {
+    typedef OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE> type;
+};
+#ifndef MVX_NO_MX // (A/B builds)
+template <bool GAUSS, bool LANE_RANGE>
+struct SlabOps<32, GAUSS, false, LANE_RANGE> {
+    typedef OpsMx32<GAUSS, LANE_RANGE> type;
+};
+#endif
 
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     voxelize_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
                     const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
-                    int *__restrict__ overflow, const VoxParams P) {
-    typedef OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE> Ops;
+                    const VoxParams P) {
+    typedef typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE>::type Ops;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1339,7 +1568,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     int sx, sy, zc;
     decode_slab(t, P, sx, sy, zc);
     const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
-    const LaneCtx L = make_lane_ctx(lane, wave, x0, y0, z0, zc * NW, cc * CT, P);
+    const LaneCtx L = Ops::ctx(lane, wave, x0, y0, z0, zc * NW, cc * CT, P);
 
     typename Ops::Acc acc;
     Ops::zero(acc);
@@ -1349,22 +1578,40 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     const int64_t a0 = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane(hdr.y);
     VK_STAMP(1); // the line has arrived
     const int RW = 8 * NW < 64 ? 8 * NW : 64; // rows staged per round
-    if (n_hdr > (unsigned)LINE_CAP) { // LINE_OVERFLOW: more candidates than line + extension hold, left to voxelize_dense_kernel
-        if (tid == 0) {
-            const int pos = atomicAdd(overflow, 1);
-            overflow[1 + pos] = (int)((unsigned)(b * P.ncc + cc) * gridDim.x + t);
-        }
-        return;
-    }
     if (n_hdr > 0) {
+        // The normal case is one round over the slab's line (<= 63 candidates, cfg-2: ~45). More candidates than one round
+        // of rows (dense slabs: larger radii) take further rounds over the line and its extension, the accumulators carried
+        // along. (Round 1 sent such slabs to a second kernel with two workgroups per compute unit: with a 1.5 A radius on
+        // cfg-2 that launch took 230 of the step's 618 us.)
+        // LINE_OVERFLOW - more candidates than line + extension hold (dense clusters; never at protein densities): the
+        // slab's "line" then is the (molecule, x-slab) list itself, any length, in atom order (entry e >= 1 at
+        // list[XL_HEADER - 1 + e]): every listed atom's row is staged, and the row filter drops the ones that miss the
+        // slab's y rows. (Until round 3 such slabs were queued for that second kernel, whose launch cost 4.7 us per call
+        // whether or not the queue was empty.)
+        const bool xl = __builtin_expect(n_hdr > (unsigned)LINE_CAP, 0);
         const uint2 *__restrict__ ext = slist_ext + ((size_t)b * (size_t)gridDim.x + t) * EXT_SLOTS;
-        line_round_scalar<Ops>(acc, line, ext, 0, (int)n_hdr, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
-        // more candidates than one round of rows (dense slabs: larger radii): further rounds over the line and its
-        // extension, the accumulators carried along. (Round 1 sent such slabs to voxelize_dense_kernel's two workgroups
-        // per compute unit: with a 1.5 A radius on cfg-2 that launch took 230 of the step's 618 us.)
-        for (int e0 = RW; e0 <= (int)n_hdr; e0 += RW) {
+        int n = (int)n_hdr;
+        if (xl) {
+            // (xbin_kernel left the list's address in entry 1, for overflowing slabs only. An address rebuilt from loaded
+            // words is, to the compiler, a per-lane pointer into any address space: left at that, EVERY line entry of
+            // the hot path below is fetched with flat_load through the vector memory pipeline - behind the stores - instead
+            // of s_load: cfg-2 x 256 ran at 0.635 of peak against 0.79. Hence the explicit scalar halves and the global
+            // address space.)
+            const uint2 where = line[1];
+            const unsigned long long at = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)where.y) << 32) |
+                                          (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)where.x);
+            typedef const uint2 __attribute__((address_space(1))) *global_u2;
+            const global_u2 xlp = (global_u2)at;
+            n = __builtin_amdgcn_readfirstlane((int)xlp[0].x);
+            line = (const uint2 *)(xlp + (XL_HEADER - 1));
+            ext = line + SLOTS;
+        }
+        // (the first round is peeled: it is staged before the accumulators exist - with 32 accumulators live across the
+        // staging loads the kernel needs 90 VGPRs instead of 62 - and the normal case is this one round)
+        line_round_scalar<Ops>(xl, acc, line, ext, 0, n, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
+        for (int e0 = RW; e0 <= n; e0 += RW) {
             __syncthreads(); // every wave is done with the previous round's rows
-            line_round_scalar<Ops>(acc, line, ext, e0, (int)n_hdr, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
+            line_round_scalar<Ops>(xl, acc, line, ext, e0, n, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
         }
     }
     Ops::write(acc, n_hdr > 0, un, tid, lane, wave, NW, b, L, x0, y0, z0, out, P);
@@ -1381,8 +1628,7 @@ __global__ void __launch_bounds__(MAXT, WPE)
     voxelize_dense_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ xlist,
                           const uint2 *__restrict__ slist, const uint2 *__restrict__ slist_ext,
                           const int64_t *__restrict__ offsets, int64_t n_one, const double *__restrict__ Tc,
-                          const float *__restrict__ kc, void *__restrict__ out, const int *__restrict__ overflow,
-                          const VoxParams P, unsigned T, unsigned total) {
+                          const float *__restrict__ kc, void *__restrict__ out, const VoxParams P, unsigned T, unsigned total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SW = Ops::SW;
     constexpr int CT = Ops::CT;
@@ -1396,11 +1642,9 @@ __global__ void __launch_bounds__(MAXT, WPE)
     unsigned *zr_l = reinterpret_cast<unsigned *>(smem + 4 * LCAP);
     int *nlist_s = reinterpret_cast<int *>(smem + 8 * LCAP);
     unsigned *un = reinterpret_cast<unsigned *>(smem + 8 * LCAP + 16);
-    const unsigned count = overflow ? (unsigned)overflow[0] : total;
     const int RW = 8 * NW < 64 ? 8 * NW : 64;
 
-    for (unsigned item = blockIdx.x; item < count; item += gridDim.x) {
-        const unsigned id = overflow ? (unsigned)overflow[1 + item] : item;
+    for (unsigned id = blockIdx.x; id < total; id += gridDim.x) {
         const unsigned z = id / T, t = id - z * T;
         int b = (int)z, cc = 0;
         if (P.ncc > 1) {
@@ -2032,7 +2276,7 @@ static void launch_profiled(K kern, dim3 grid, dim3 block, size_t lds, hipStream
 }
 
 template <typename Ops, int MAXT = 1024, int WPE = 1>
-static hipError_t launch_dense(const VoxArgs &a, const int *overflow, size_t lds, unsigned grid, unsigned total, hipStream_t s) {
+static hipError_t launch_dense(const VoxArgs &a, size_t lds, unsigned grid, unsigned total, hipStream_t s) {
     static LdsLimit raised;
     const VoxParams &p = a.p;
     if (p.NW * 64 > MAXT) return hipErrorInvalidConfiguration;
@@ -2040,7 +2284,7 @@ static hipError_t launch_dense(const VoxArgs &a, const int *overflow, size_t lds
     hipError_t e = raise_lds_limit(kern, lds, raised);
     if (e != hipSuccess) return e;
     launch_profiled(kern, dim3(grid), dim3(p.NW * 64), lds, s, a.rec, a.w, a.xlist, a.slist, a.slist_ext, a.offsets, a.n_one, a.Tc, a.kc,
-                    a.out, overflow, a.p, (unsigned)(p.nzc * p.nsy * p.nsx), total);
+                    a.out, a.p, (unsigned)(p.nzc * p.nsy * p.nsx), total);
     return hipGetLastError();
 }
 
@@ -2054,22 +2298,14 @@ struct LaunchFn {
         if (nb <= 0) return hipSuccess;
         if ((long long)nb * p.ncc > 65535) return hipErrorInvalidConfiguration;
         static LdsLimit raised;
-        const size_t lds = voxelize_lds_bytes(CT, p.NW, MVX_CR);
+        const bool mx = std::is_same<typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE>::type, OpsMx32<GAUSS, LANE_RANGE>>::value;
+        const size_t lds = mx ? voxelize_mx_lds_bytes(p.NW) : voxelize_lds_bytes(CT, p.NW, MVX_CR);
         auto kern = &voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>;
         hipError_t e = raise_lds_limit(kern, lds, raised);
         if (e != hipSuccess) return e;
         launch_profiled(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), lds, s, a.rec, a.w,
-                        a.slist, a.slist_ext, a.Tc, a.kc, static_cast<float *>(a.out), a.overflow, a.p);
+                        a.slist, a.slist_ext, a.Tc, a.kc, static_cast<float *>(a.out), a.p);
         return hipGetLastError();
-    }
-};
-
-struct DenseFn {
-    const VoxArgs &a;
-    hipStream_t s;
-    template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
-    hipError_t operator()() const {
-        return launch_dense<OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE>>(a, a.overflow, dense_lds_bytes(CT, a.p.NW), a.dense_grid ? a.dense_grid : 512u, 0u, s);
     }
 };
 
@@ -2087,9 +2323,9 @@ struct Dense64Fn {
             // 32 float64 accumulators per lane: 512-thread workgroups (the plan's slabs have at most 8 waves), so the
             // kernel may use 256 VGPRs; one chunk instead of two halves the staging, distance and exp work per slab
             if (p.NW > 8) return hipErrorInvalidValue;
-            return launch_dense<OpsF64<CT, GAUSS, CHANWISE, LANE_RANGE>, 512>(a, nullptr, dense64_lds_bytes(CT, p.NW), grid, (unsigned)total, s);
+            return launch_dense<OpsF64<CT, GAUSS, CHANWISE, LANE_RANGE>, 512>(a, dense64_lds_bytes(CT, p.NW), grid, (unsigned)total, s);
         } else {
-            return launch_dense<OpsF64<CT, GAUSS, CHANWISE, LANE_RANGE>>(a, nullptr, dense64_lds_bytes(CT, p.NW), grid, (unsigned)total, s);
+            return launch_dense<OpsF64<CT, GAUSS, CHANWISE, LANE_RANGE>>(a, dense64_lds_bytes(CT, p.NW), grid, (unsigned)total, s);
         }
     }
 };
@@ -2133,11 +2369,6 @@ hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float
 hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {
     KernelKey k{ct, gauss, chanwise, chanwise ? true : lane_range, a.p.NW <= 8 ? 512 : 1024};
     return for_kernel(k, LaunchFn{a, nb, s});
-}
-
-hipError_t launch_voxelize_dense(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {
-    KernelKey k{ct, gauss, chanwise, chanwise ? true : lane_range, a.p.NW <= 8 ? 512 : 1024};
-    return for_kernel(k, DenseFn{a, s});
 }
 
 hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {

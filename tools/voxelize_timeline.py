@@ -32,7 +32,7 @@ if CFG5:
 else:
     wl = W.cfg2(batch=B)
     vox = molvoxel_amd.create_voxelizer(0.5, 64, library="hip")
-    radii = 1.0
+    radii = float(os.environ.get("RADIUS", "1.0"))  # scalar radius in Angstrom (cfg-2 itself: 1.0)
     nwg = B * 512
 coords = vox.asarray(np.concatenate(wl.coords[:B]), "coords")
 feats = vox.asarray(np.concatenate(wl.channels[:B]), "features")
@@ -53,7 +53,7 @@ t = t[ok]
 kc = lambda a, b: (t[:, b] - t[:, a]) / 1000.0
 def line(name, x):
     print(f"{name:34s} p10 {np.percentile(x, 10):6.2f}  p50 {np.percentile(x, 50):6.2f}  p90 {np.percentile(x, 90):6.2f}  mean {x.mean():6.2f}")
-print(f"{'cfg-5' if CFG5 else 'cfg-2'} x {B}: {int(ok.sum())} non-empty workgroups of {nwg}; candidates per line p50 {np.median(n[ok]):.0f} max {n[ok].max():.0f}")
+print(f"{'cfg-5' if CFG5 else 'cfg-2'} x {B}" + ("" if CFG5 else f" radius {radii}") + f": {int(ok.sum())} non-empty workgroups of {nwg}; candidates per line p50 {np.median(n[ok]):.0f} max {n[ok].max():.0f}")
 print("phase (kilocycles per workgroup)")
 line("line load             0 -> 1", kc(0, 1))
 line("row loads + LDS       1 -> 2", kc(1, 2))
