@@ -413,6 +413,17 @@ int run(mvx_handle *h, const RunArgs &r) {
         }
     }
 
+    // Channel counts that are not a multiple of the chunk width (C = 33 ... 63, 65 ...): the binned float32 pipeline runs
+    // the full chunks with the wide kernel and the remainder with the narrowest kernel that holds it (C = 33: 32 + 1,
+    // C = 40: 32 + 8) - a second, small voxelize launch over the same candidate lines - instead of a whole extra chunk of
+    // `ct` accumulators that are mostly padding (C = 33 cost +49 % for +3 % of the bytes).
+    int nfull = ncc, ct_rem = 0;
+    if (!f64 && !direct && ncc > 1 && r.C % ct != 0) {
+        ct_rem = pick_ct(r.C - (r.C / ct) * ct);
+        if (ct_rem < ct) nfull = r.C / ct;
+        else ct_rem = 0; // (a remainder of more than half a chunk needs the wide kernel anyway: one launch, as before)
+    }
+
     // ---- molecules in chunks (gridDim.y limit; optionally pre-pass on the side stream, one chunk ahead) ----------
     const int max_mol = 65535 / ncc;
     int nchunk = (r.B + max_mol - 1) / max_mol;
@@ -479,7 +490,8 @@ int run(mvx_handle *h, const RunArgs &r) {
 
     // ---- workspace --------------------------------------------------------------------------------
     const size_t n_alloc = (size_t)std::max<int64_t>(total, 1);
-    const int Cpad = (ncc > 1) ? ncc * ct : (ct < 4 ? 4 : ct); // channel weights per atom, zero padded
+    // channel weights per atom, zero padded
+    const int Cpad = ct_rem ? nfull * ct + (ct_rem < 4 ? 4 : ct_rem) : ((ncc > 1) ? ncc * ct : (ct < 4 ? 4 : ct));
     // feature rows that already are Cpad wide are read in place; anything else (one-hot types, 1, padding) is packed
     const bool direct_w = (r.mode == MODE_FEATURES && r.C == Cpad);
     const size_t nslabs = (size_t)r.B * sp.per_molecule();
@@ -501,10 +513,14 @@ int run(mvx_handle *h, const RunArgs &r) {
     void *d_rmax = nullptr;
     double *d_Tc = nullptr;
     float *d_kc = nullptr;
+    ChanGroups *d_groups = nullptr;
     if (chanwise && !direct) {
-        const size_t tc_off = 16, kc_off = tc_off + align_up((size_t)r.C * sizeof(double), 16);
+        // [max radius | ChanGroups | per-channel thresholds | per-channel coefficients] (the per-channel kernel finds the
+        // table right below its thresholds)
+        const size_t tc_off = 16 + align_up(sizeof(ChanGroups), 16), kc_off = tc_off + align_up((size_t)r.C * sizeof(double), 16);
         if ((rc = ensure(w.aux, kc_off + (size_t)r.C * sizeof(double)))) return rc; // (float64 handles: double coefficients)
         d_rmax = w.aux.p;
+        d_groups = reinterpret_cast<ChanGroups *>((char *)w.aux.p + 16);
         d_Tc = reinterpret_cast<double *>((char *)w.aux.p + tc_off);
         d_kc = reinterpret_cast<float *>((char *)w.aux.p + kc_off);
         if (f64)
@@ -512,7 +528,7 @@ int run(mvx_handle *h, const RunArgs &r) {
                                       static_cast<double *>(d_rmax), d_Tc, reinterpret_cast<double *>(d_kc), overlap ? pre : s));
         else
             HIP_TRY(launch_chan_aux(static_cast<const float *>(in.radii), r.C, h->cfg.density, h->sigma32,
-                                    static_cast<float *>(d_rmax), d_Tc, d_kc, overlap ? pre : s));
+                                    static_cast<float *>(d_rmax), d_Tc, d_kc, d_groups, overlap ? pre : s));
     }
 
     // ---- kernel arguments -------------------------------------------------------------------------
@@ -572,6 +588,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.nsy_inv = umulhi_inverse(sp.nsy);
     va.p.nzc_inv = umulhi_inverse(sp.nzc);
     va.p.b0 = 0;
+    va.p.c0 = 0;
     va.p.NW = sp.NW;
     va.p.w_stride = Cpad;
     va.p.dcap = f64 ? 64 : voxelize_dcap(ct, sp.NW);
@@ -658,8 +675,31 @@ int run(mvx_handle *h, const RunArgs &r) {
             if (interleave && (rc = prepass(k))) return rc;
             if (side_stream) HIP_TRY(hipStreamWaitEvent(s, overlap ? w.ev_pre : h->ev_pre[k], 0));
             va.p.b0 = b0;
+            if (chanwise) {
+                // channels grouped by radius (chan_aux_kernel): one workgroup per (slab, molecule, slot), each slot's
+                // membership and density evaluated once for all its channels; feature rows are read in place through
+                // the slot's channel list. The per-channel launch below returns at once unless the radii did not fit
+                // the slots.
+                VoxArgs vm = va;
+                vm.w = reinterpret_cast<const unsigned *>(in.channels);
+                vm.p.w_stride = r.C;
+                vm.p.ncc = CHAN_GROUP_SLOTS;
+                vm.Tc = reinterpret_cast<const double *>(d_groups);
+                const int per = 65535 / CHAN_GROUP_SLOTS;
+                for (int m0 = b0; m0 < b1; m0 += per) {
+                    vm.p.b0 = m0;
+                    if ((rc = timed_launch(h, s, [&] { return launch_voxelize_mapped(vm, std::min(per, b1 - m0), gauss, lane_range, s); }))) return rc;
+                }
+            }
+            va.p.ncc = nfull;
+            va.p.c0 = 0;
             // the bracket holds voxelize_kernel alone (what rocprofv3 reports under that name)
             if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, ct, gauss, chanwise, lane_range, s); }))) return rc;
+            if (ct_rem) { // the remainder channels [nfull * ct, C) with a narrower kernel
+                va.p.ncc = 1;
+                va.p.c0 = nfull * ct;
+                if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, ct_rem, gauss, chanwise, lane_range, s); }))) return rc;
+            }
         }
     }
 

@@ -236,7 +236,7 @@ __device__ __forceinline__ int find_molecule(const int64_t *offsets, int B, int6
 // channel-wise auxiliary: max radius (float32), per-channel thresholds / coefficients
 // ------------------------------------------------------------------------------------------------
 __global__ void chan_aux_kernel(const float *radii, int C, int density, float sigma32, float *rmax, double *Tc,
-                                float *kc) {
+                                float *kc, ChanGroups *groups) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const float r = radii[c];
         Tc[c] = d2_threshold(r);
@@ -246,6 +246,30 @@ __global__ void chan_aux_kernel(const float *radii, int C, int density, float si
         float m = radii[0];
         for (int c = 1; c < C; ++c) m = radii[c] > m ? radii[c] : m;
         rmax[0] = m;
+        // channels with the same radius (same float32 bits) -> slots of at most 32 channels, in channel order
+        int nslots = 0, fallback = 0;
+        unsigned bits[CHAN_GROUP_SLOTS];
+        for (int c = 0; c < C && !fallback; ++c) {
+            const unsigned rb = __float_as_uint(radii[c]);
+            int slot = -1;
+            for (int g = 0; g < nslots; ++g)
+                if (bits[g] == rb && groups->g[g].nch < 32) slot = g;
+            if (slot < 0) {
+                if (nslots == CHAN_GROUP_SLOTS) {
+                    fallback = 1;
+                    break;
+                }
+                slot = nslots++;
+                bits[slot] = rb;
+                groups->g[slot].T = d2_threshold(radii[c]);
+                groups->g[slot].k = density == MVX_GAUSSIAN ? gauss_coeff(radii[c], sigma32) : 0.0f;
+                groups->g[slot].nch = 0;
+                for (int j = 0; j < 32; ++j) groups->g[slot].ch[j] = -1;
+            }
+            groups->g[slot].ch[groups->g[slot].nch++] = c;
+        }
+        groups->nslots = nslots;
+        groups->fallback = fallback;
     }
 }
 
@@ -269,8 +293,8 @@ hipError_t launch_chan_aux64(const double *radii, int32_t C, int32_t density, do
 }
 
 hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax, double *Tc,
-                           float *kc, hipStream_t s) {
-    hipLaunchKernelGGL(chan_aux_kernel, dim3(1), dim3(256), 0, s, radii, C, density, sigma32, rmax, Tc, kc);
+                           float *kc, ChanGroups *groups, hipStream_t s) {
+    hipLaunchKernelGGL(chan_aux_kernel, dim3(1), dim3(256), 0, s, radii, C, density, sigma32, rmax, Tc, kc, groups);
     return hipGetLastError();
 }
 
@@ -919,6 +943,10 @@ size_t dense64_lds_bytes(int32_t ct, int32_t NW) {
 struct LaneCtx {
     double gx, gy, gz; // voxel centre: axis[i] = i*res - width/2 (numpy/voxelizer.py:41-43)
     double gx1;        // OpsMx32 only (two voxels per lane: (ix, iy, iz) and (ix + 1, iy, iz)): the second voxel's x
+    double Tg;         // mapped launches (channel-wise features grouped by radius) only: the slot's threshold, coefficient
+    float kg;          // ... and, for the lanes that stage channel weights, the feature column they read (-1: none)
+    int wcol;
+    const int *cmap;   // ... and the slot's channel list (LDS copy): channel of accumulator c, -1 = none
     int ix, iy, iz;
     int zt_w;          // this wave's sub-tile index along z
     int cbase;         // first channel of this workgroup's chunk
@@ -992,10 +1020,11 @@ __device__ __forceinline__ void accumulate_row(float2v (&acc)[(CT + 1) / 2], con
 
 // Write-out of one slab. `any` false: zero fill without the LDS round trip. Begins with a barrier (the union region
 // may still hold candidate rows) and ends without one.
-template <int CT, int CRMAX = MVX_CR>
+// MAPPED: accumulator c belongs to channel cmap[c] (-1: to none) instead of cbase + c
+template <int CT, int CRMAX = MVX_CR, bool MAPPED = false>
 __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], bool any, float *tile, int tid, int lane,
                                            int wave, int NW, int b, int cbase, int x0, int y0, int z0, float *out,
-                                           const VoxParams &P) {
+                                           const VoxParams &P, const int *cmap = nullptr) {
     constexpr int CR = CT < CRMAX ? CT : CRMAX; // channels per write-out round
     constexpr int NROUND = CT / CR;
     const int D = P.D;
@@ -1007,7 +1036,7 @@ __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], b
     const int zq = z0 + 4 * q;
     const int sxx = (rfirst >> SUBY_SH) & (SUBX - 1), syy = rfirst & (SUBY - 1), cfirst = rfirst / RPC;
     const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
-    float *dst0 = out + ((size_t)b * P.C + cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
+    float *dst0 = out + ((size_t)b * P.C + (MAPPED ? 0 : cbase + cfirst)) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
     if (!any) {
         // Pacing: a workgroup that has nothing to compute would fire its 64 KB of stores the moment it starts; holding
         // them back ~1.7 us (4096 cycles) lets the store streams of the resident workgroups interleave: ligand batches
@@ -1018,8 +1047,9 @@ __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], b
 #pragma unroll
             for (int p = 0; p < (CT + 3) / 4; ++p) {
                 const int c = cfirst + 4 * p;
-                if (c < CT && cbase + c < P.C) {
-                    float *dst = dst0 + (size_t)(4 * p) * D3;
+                const int mc = (MAPPED && c < CT) ? cmap[c] : 0;
+                if (c < CT && (MAPPED ? mc >= 0 : cbase + c < P.C)) {
+                    float *dst = dst0 + (size_t)(MAPPED ? mc : 4 * p) * D3;
                     if (P.vec_store) {
                         store_f4(dst, make_float4(0.f, 0.f, 0.f, 0.f), P.store_kind);
                     } else {
@@ -1050,9 +1080,10 @@ __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], b
 #pragma unroll
             for (int p = 0; p < (CR + 3) / 4; ++p) {
                 const int c = cfirst + 4 * p; // channel inside the round
-                if (c < CR && cbase + rd * CR + c < P.C) {
+                const int mc = (MAPPED && c < CR) ? cmap[rd * CR + c] : 0;
+                if (c < CR && (MAPPED ? mc >= 0 : cbase + rd * CR + c < P.C)) {
                     const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 4 * RPC * p) * RS + 4 * q);
-                    float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
+                    float *dst = dst0 + (size_t)(MAPPED ? mc : rd * CR + 4 * p) * D3;
                     if (P.vec_store) {
                         store_f4(dst, v, P.store_kind);
                     } else {
@@ -1175,9 +1206,10 @@ __device__ __forceinline__ void accumulate_row64(double (&acc)[CT], const unsign
 // What differs between float32 and float64 grids: accumulator type, staged row width, the per-candidate update
 // and the write-out. OpsF32 is the tuned path; OpsF64 favours exactness over speed (8-B stores straight from
 // registers, no LDS transposition).
-template <int CT_, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+template <int CT_, bool GAUSS, bool CHANWISE, bool LANE_RANGE, bool MAPPED_ = false>
 struct OpsF32 {
     static constexpr int CT = CT_;
+    static constexpr bool MAPPED = MAPPED_;
     typedef float2v Acc[(CT + 1) / 2];
     static constexpr int WORDS = 1;                   // 32-bit words per channel weight
     static constexpr int WW = CT;                     // weight words staged per row
@@ -1204,8 +1236,8 @@ struct OpsF32 {
     }
     static __device__ __forceinline__ void write(const Acc &acc, bool any, unsigned *un, int tid, int lane, int wave, int NW,
                                                  int b, const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
-        write_slab<CT>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
-                       static_cast<float *>(out), P);
+        write_slab<CT, MVX_CR, MAPPED>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
+                                       static_cast<float *>(out), P, MAPPED ? L.cmap : nullptr);
     }
     // per-molecule launches (voxelize_direct_kernel): 16 channels per round - two rounds, four barriers; the small
     // rounds pay when thousands of workgroups' store bursts interleave, not when 512 workgroups store once (cfg-2
@@ -1243,9 +1275,10 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int MX_CR = 8; // channels per write-out round of the matrix-core path
 size_t voxelize_mx_lds_bytes(int32_t NW) { return voxelize_lds_bytes(32, NW, MX_CR); }
 
-template <bool GAUSS, bool LANE_RANGE>
+template <bool GAUSS, bool LANE_RANGE, bool MAPPED_ = false>
 struct OpsMx32 {
     static constexpr int CT = 32;
+    static constexpr bool MAPPED = MAPPED_;
     struct Acc {
         f16v p0, p1; // the x0 plane and the x0 + 1 plane of the sub-tile
     };
@@ -1317,7 +1350,8 @@ struct OpsMx32 {
         float *out = static_cast<float *>(out_);
         if (!any) { // zero fill without the LDS round trip: the one-voxel-per-lane code (no accumulator is read)
             float2v zero[16];
-            write_slab<32>(zero, false, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0, out, P);
+            write_slab<32, MVX_CR, MAPPED>(zero, false, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0, out, P,
+                                           MAPPED ? L.cmap : nullptr);
             return;
         }
         float *tile = reinterpret_cast<float *>(un);
@@ -1330,7 +1364,7 @@ struct OpsMx32 {
         const int q = tid % F4, rfirst = tid / F4, zq = z0 + 4 * q;
         const int sxx = (rfirst >> SUBY_SH) & (SUBX - 1), syy = rfirst & (SUBY - 1), cfirst = rfirst / RPC;
         const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
-        float *dst0 = out + ((size_t)b * P.C + L.cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
+        float *dst0 = out + ((size_t)b * P.C + (MAPPED ? 0 : L.cbase + cfirst)) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
         // this lane's voxel column in the tile, and the first of its four channels of a round
         const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1), h = lane >> 5;
         float *mine = tile + (4 * h * RPC + ly) * RS + SUBZ * wave + lz; // + (c * RPC + x * SUBY) * RS
@@ -1349,9 +1383,10 @@ struct OpsMx32 {
 #pragma unroll
                 for (int p = 0; p < (CR + 3) / 4; ++p) {
                     const int c = cfirst + 4 * p; // channel inside the round
-                    if (c < CR && L.cbase + rd * CR + c < P.C) {
+                    const int mc = (MAPPED && c < CR) ? L.cmap[rd * CR + c] : 0;
+                    if (c < CR && (MAPPED ? mc >= 0 : L.cbase + rd * CR + c < P.C)) {
                         const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 4 * RPC * p) * RS + 4 * q);
-                        float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
+                        float *dst = dst0 + (size_t)(MAPPED ? mc : rd * CR + 4 * p) * D3;
                         if (P.vec_store) {
                             store_f4(dst, v, P.store_kind);
                         } else {
@@ -1487,7 +1522,8 @@ __device__ __forceinline__ void line_round_scalar(const bool xl, typename Ops::A
     // round e0 / RW of the slab's candidates: row slot sl holds entry e0 + sl of the line (entries 1..n_line; entry e sits
     // at line[e] up to SLOTS-1 and at ext[e - SLOTS] beyond)
     constexpr int SW = Ops::SW;
-    const unsigned *src = lane < 16 ? rec + lane : w + (Ops::WORDS * L.cbase + lane - 16);
+    // (mapped launches: the weight lanes read the feature columns of the slot's channel list)
+    const unsigned *src = lane < 16 ? rec + lane : w + (Ops::MAPPED ? (L.wcol < 0 ? 0 : L.wcol) : Ops::WORDS * L.cbase + lane - 16);
     const size_t stride = lane < 16 ? (size_t)16 : (size_t)(Ops::WORDS * P.w_stride);
     const bool stager = lane < 16 + Ops::WW;
     int ai[8];
@@ -1502,6 +1538,16 @@ __device__ __forceinline__ void line_round_scalar(const bool xl, typename Ops::A
         const int e = e0 + wave + u * NW;
         v[u] = 0u;
         if (e >= 1 && e <= n_line && stager) v[u] = src[(size_t)(a0 + ai[u]) * stride];
+    }
+    if (Ops::MAPPED) {
+        // the slot's radius instead of the record's (which holds max(radii): the culls' radius, numpy/voxelizer.py:138):
+        // words 6-7 of a row are T, word 8 is k; weight lanes beyond the slot's channels stage zeros
+        const unsigned long long tb = (unsigned long long)__double_as_longlong(L.Tg);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v[u] = lane == 6 ? (unsigned)tb : (lane == 7 ? (unsigned)(tb >> 32) : (lane == 8 ? __float_as_uint(L.kg) : v[u]));
+            if (lane >= 16 && L.wcol < 0) v[u] = 0u;
+        }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1530,23 +1576,25 @@ __device__ __forceinline__ void line_round_scalar(const bool xl, typename Ops::A
 }
 
 // voxelize_kernel's arithmetic: 32-channel chunks go to the matrix cores (OpsMx32), everything else to the vector ALU
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, bool MAPPED>
 struct SlabOps {
-    typedef OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE> type;
+    typedef OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE, MAPPED> type;
 };
 #ifndef MVX_NO_MX // (A/B builds)
-template <bool GAUSS, bool LANE_RANGE>
-struct SlabOps<32, GAUSS, false, LANE_RANGE> {
-    typedef OpsMx32<GAUSS, LANE_RANGE> type;
+// (not the per-lane-range variants - blockdim 4, 5, 12, ...: their six extra index comparisons per voxel do not fit the
+// 64 registers of the two-voxel layout without scratch: 0.527 against 0.479 ms per 64 cfg-2 molecules at blockdim 5)
+template <bool GAUSS, bool MAPPED>
+struct SlabOps<32, GAUSS, false, false, MAPPED> {
+    typedef OpsMx32<GAUSS, false, MAPPED> type;
 };
 #endif
 
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT, bool MAPPED = false>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     voxelize_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
                     const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
                     const VoxParams P) {
-    typedef typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE>::type Ops;
+    typedef typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE, MAPPED>::type Ops;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1562,13 +1610,30 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
         cc = (int)blockIdx.y - b * P.ncc;
     }
     b += P.b0;
+    if constexpr (CHANWISE) { // the general per-channel kernel serves only what the grouped launch could not (ChanGroups)
+        const ChanGroups *G = reinterpret_cast<const ChanGroups *>(reinterpret_cast<const char *>(Tc) - sizeof(ChanGroups));
+        if (!G->fallback) return;
+    }
+    const ChanGroups *__restrict__ G = reinterpret_cast<const ChanGroups *>(Tc); // (mapped launches only)
+    if constexpr (MAPPED) {
+        if (G->fallback || cc >= G->nslots) return; // (cc = the slot: P.ncc = CHAN_GROUP_SLOTS)
+    }
     // the slab's candidate line: {count, first atom}, then {atom index, packed ranges} per candidate
     const uint2 *__restrict__ line = slist + ((size_t)b * (size_t)gridDim.x + t) * SLOTS; // (uniform: scalar loads)
     const uint2 hdr = line[0];
     int sx, sy, zc;
     decode_slab(t, P, sx, sy, zc);
     const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
-    const LaneCtx L = Ops::ctx(lane, wave, x0, y0, z0, zc * NW, cc * CT, P);
+    LaneCtx L = Ops::ctx(lane, wave, x0, y0, z0, zc * NW, MAPPED ? 0 : P.c0 + cc * CT, P);
+    if constexpr (MAPPED) {
+        int *cmap = reinterpret_cast<int *>(smem + P.dcap); // (P.dcap: bytes of the rows / tile region in mapped launches)
+        if (tid < 32) cmap[tid] = G->g[cc].ch[tid];
+        L.cmap = cmap;
+        L.Tg = G->g[cc].T;
+        L.kg = G->g[cc].k;
+        L.wcol = (lane >= 16 && lane < 48) ? G->g[cc].ch[lane - 16] : 0;
+        __syncthreads(); // (the list is read in the write-out, which an empty slab reaches without another barrier)
+    }
 
     typename Ops::Acc acc;
     Ops::zero(acc);
@@ -2288,6 +2353,32 @@ static hipError_t launch_dense(const VoxArgs &a, size_t lds, unsigned grid, unsi
     return hipGetLastError();
 }
 
+struct MappedFn {
+    const VoxArgs &a;
+    int32_t nb;
+    hipStream_t s;
+    template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT>
+    hipError_t operator()() const {
+        if constexpr (CT != 32 || CHANWISE) {
+            return hipErrorInvalidValue;
+        } else {
+            VoxParams p = a.p;
+            if (nb <= 0) return hipSuccess;
+            if ((long long)nb * p.ncc > 65535) return hipErrorInvalidConfiguration;
+            static LdsLimit raised;
+            const bool mx = std::is_same<typename SlabOps<CT, GAUSS, false, LANE_RANGE, true>::type, OpsMx32<GAUSS, LANE_RANGE, true>>::value;
+            const size_t main_lds = mx ? voxelize_mx_lds_bytes(p.NW) : voxelize_lds_bytes(CT, p.NW, MVX_CR);
+            p.dcap = (int32_t)main_lds; // where the slot's channel list sits in LDS
+            auto kern = &voxelize_kernel<CT, GAUSS, false, LANE_RANGE, MAXT, true>;
+            hipError_t e = raise_lds_limit(kern, main_lds + 128, raised);
+            if (e != hipSuccess) return e;
+            launch_profiled(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), main_lds + 128, s, a.rec, a.w,
+                            a.slist, a.slist_ext, a.Tc, a.kc, static_cast<float *>(a.out), p);
+            return hipGetLastError();
+        }
+    }
+};
+
 struct LaunchFn {
     const VoxArgs &a;
     int32_t nb;
@@ -2298,7 +2389,7 @@ struct LaunchFn {
         if (nb <= 0) return hipSuccess;
         if ((long long)nb * p.ncc > 65535) return hipErrorInvalidConfiguration;
         static LdsLimit raised;
-        const bool mx = std::is_same<typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE>::type, OpsMx32<GAUSS, LANE_RANGE>>::value;
+        const bool mx = std::is_same<typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE, false>::type, OpsMx32<GAUSS, LANE_RANGE, false>>::value;
         const size_t lds = mx ? voxelize_mx_lds_bytes(p.NW) : voxelize_lds_bytes(CT, p.NW, MVX_CR);
         auto kern = &voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>;
         hipError_t e = raise_lds_limit(kern, lds, raised);
@@ -2369,6 +2460,11 @@ hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float
 hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {
     KernelKey k{ct, gauss, chanwise, chanwise ? true : lane_range, a.p.NW <= 8 ? 512 : 1024};
     return for_kernel(k, LaunchFn{a, nb, s});
+}
+
+hipError_t launch_voxelize_mapped(const VoxArgs &a, int32_t nb, bool gauss, bool lane_range, hipStream_t s) {
+    KernelKey k{32, gauss, false, lane_range, a.p.NW <= 8 ? 512 : 1024};
+    return for_kernel(k, MappedFn{a, nb, s});
 }
 
 hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {

@@ -875,6 +875,44 @@ def test_overlapped_prepass_equals_serial_calls(mv):
         assert torch.equal(fast.forward_batch(dev[1][0], dev[1][2], None, dev[1][1], dev[1][3], num_channels=dev[1][4]), want[1])
 
 
+@pytest.mark.parametrize("C_,distinct,D,blockdim", [(32, 4, 32, None), (40, 2, 32, None), (12, 9, 24, None), (32, 1, 32, None),
+                                                    (7, 3, 27, 5), (64, 8, 16, None), (33, 33, 16, None)])
+@pytest.mark.parametrize("density", ["gaussian", "binary"])
+def test_channel_wise_features_grouped_by_radius(mv, C_, distinct, D, blockdim, density):
+    """Channel-wise radii for features (numpy/voxelizer.py:213-224): channels that share a radius share the membership test
+    and the density. The batched pipeline sorts the channels into at most 8 slots of at most 32 channels by radius on
+    the device and runs one workgroup per (slab, molecule, slot); radii that do not fit (9 distinct values, 33 distinct
+    values) fall back to the per-channel kernel. Every shape against the oracle, batched (grouped) against per-molecule
+    (direct kernel, per-channel), and a 40-channel group that spans two slots."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(1000 * C_ + distinct)
+    W_ = 0.5 * (D - 1)
+    sizes = [900, 30, 0, 1400]
+    off = np.cumsum([0] + sizes)
+    xyz = rng.uniform(-W_ / 2 - 1.5, W_ / 2 + 1.5, (off[-1], 3))
+    feat = (rng.random((off[-1], C_)) - 0.25).astype(np.float32)
+    pool = rng.uniform(0.7, 1.9, distinct).astype(np.float32)
+    radii = pool[rng.integers(0, distinct, C_)]
+    radii[:distinct] = pool  # every value occurs
+    extra = {"blockdim": blockdim} if blockdim else {}
+    v = mv.create_voxelizer(0.5, D, "channel-wise", density, "hip", output="numpy", sigma=0.6, **extra)
+    v.debug_option("direct", 0)
+    got = v.forward_batch(xyz, off, None, feat, radii)
+    one = mv.create_voxelizer(0.5, D, "channel-wise", density, "hip", output="numpy", sigma=0.6, **extra)
+    one.debug_option("direct", 1)
+    for b in range(len(sizes)):
+        lo, hi = off[b], off[b + 1]
+        ref = c_oracle.voxelize(xyz[lo:hi], feat[lo:hi], radii, resolution=0.5, dimension=D, radii_type="channel-wise",
+                                density=density, sigma=0.6, num_channels=C_, blockdim=blockdim)
+        if density == "binary":
+            assert np.array_equal(got[b] != 0, ref != 0) and np.abs(got[b] - ref).max() <= 1e-6
+        else:
+            assert_gaussian(got[b], ref)
+        if hi > lo:
+            assert np.array_equal(got[b], one.forward_features(xyz[lo:hi], None, feat[lo:hi], radii)), b
+
+
 def test_per_molecule_calls_with_overlap_enabled_wait_for_their_converted_inputs(mv):
     """overlap_prepass concerns batched calls only (mvx.h: "the batched three-launch path"). A per-molecule forward() on
     such a handle - binned route (a cfg-5-sized molecule), float32 device coords and a float32 device centre that this

@@ -46,6 +46,8 @@ run("cfg-2 (features C=32, scalar r=1.0, gaussian)", 64, "scalar", "gaussian", "
 run("binary instead of gaussian", 64, "scalar", "binary", "features", 32, 1.0)
 run("atom-wise radii 0.8-1.2", 64, "atom-wise", "gaussian", "features", 32, r_atom)
 run("channel-wise radii 0.8-1.2 (features)", 64, "channel-wise", "gaussian", "features", 32, rng.uniform(0.8, 1.2, 32).astype(np.float32))
+run("channel-wise radii, 32 channels, 4 distinct radii", 64, "channel-wise", "gaussian", "features", 32, np.repeat(np.float32([0.85, 0.95, 1.05, 1.15]), 8))
+run("channel-wise radii, 32 channels, 1 radius", 64, "channel-wise", "gaussian", "features", 32, np.full(32, 1.0, np.float32))
 run("forward_types, 8 types, gaussian", 64, "scalar", "gaussian", "types", 8, 1.0)
 run("forward_types, 32 types, binary", 64, "scalar", "binary", "types", 32, 1.0)
 run("forward_types, 8 types, channel-wise radii", 64, "channel-wise", "gaussian", "types", 8, rng.uniform(0.8, 1.2, 8).astype(np.float32))
