@@ -514,11 +514,14 @@ int run(mvx_handle *h, const RunArgs &r) {
     double *d_Tc = nullptr;
     float *d_kc = nullptr;
     ChanGroups *d_groups = nullptr;
+    int32_t *d_chan_slot = nullptr;
     if (chanwise && !direct) {
         // [max radius | ChanGroups | per-channel thresholds | per-channel coefficients] (the per-channel kernel finds the
         // table right below its thresholds)
         const size_t tc_off = 16 + align_up(sizeof(ChanGroups), 16), kc_off = tc_off + align_up((size_t)r.C * sizeof(double), 16);
-        if ((rc = ensure(w.aux, kc_off + (size_t)r.C * sizeof(double)))) return rc; // (float64 handles: double coefficients)
+        const size_t slot_off = kc_off + align_up((size_t)r.C * sizeof(double), 16); // the channels' radius slots (int32 x C)
+        if ((rc = ensure(w.aux, slot_off + (size_t)r.C * sizeof(int32_t)))) return rc; // (float64 handles: double coefficients)
+        d_chan_slot = reinterpret_cast<int32_t *>((char *)w.aux.p + slot_off);
         d_rmax = w.aux.p;
         d_groups = reinterpret_cast<ChanGroups *>((char *)w.aux.p + 16);
         d_Tc = reinterpret_cast<double *>((char *)w.aux.p + tc_off);
@@ -528,7 +531,7 @@ int run(mvx_handle *h, const RunArgs &r) {
                                       static_cast<double *>(d_rmax), d_Tc, reinterpret_cast<double *>(d_kc), overlap ? pre : s));
         else
             HIP_TRY(launch_chan_aux(static_cast<const float *>(in.radii), r.C, h->cfg.density, h->sigma32,
-                                    static_cast<float *>(d_rmax), d_Tc, d_kc, d_groups, overlap ? pre : s));
+                                    static_cast<float *>(d_rmax), d_Tc, d_kc, d_groups, d_chan_slot, overlap ? pre : s));
     }
 
     // ---- kernel arguments -------------------------------------------------------------------------
@@ -676,19 +679,20 @@ int run(mvx_handle *h, const RunArgs &r) {
             if (side_stream) HIP_TRY(hipStreamWaitEvent(s, overlap ? w.ev_pre : h->ev_pre[k], 0));
             va.p.b0 = b0;
             if (chanwise) {
-                // channels grouped by radius (chan_aux_kernel): one workgroup per (slab, molecule, slot), each slot's
-                // membership and density evaluated once for all its channels; feature rows are read in place through
-                // the slot's channel list. The per-channel launch below returns at once unless the radii did not fit
-                // the slots.
-                VoxArgs vm = va;
-                vm.w = reinterpret_cast<const unsigned *>(in.channels);
-                vm.p.w_stride = r.C;
-                vm.p.ncc = CHAN_GROUP_SLOTS;
-                vm.Tc = reinterpret_cast<const double *>(d_groups);
-                const int per = 65535 / CHAN_GROUP_SLOTS;
+                // channels grouped by radius (chan_aux_kernel): chunks of 32 channels on the matrix-core path, one
+                // threshold test and one density per radius slot and candidate, feature rows read in place. The
+                // per-channel launch below returns at once unless there were more distinct radii than slots.
+                VoxArgs vg = va;
+                vg.w = reinterpret_cast<const unsigned *>(in.channels);
+                vg.p.w_stride = r.C;
+                vg.p.ncc = (r.C + 31) / 32;
+                vg.p.c0 = 0;
+                vg.Tc = reinterpret_cast<const double *>(d_groups);
+                vg.kc = reinterpret_cast<const float *>(d_chan_slot);
+                const int per = 65535 / vg.p.ncc;
                 for (int m0 = b0; m0 < b1; m0 += per) {
-                    vm.p.b0 = m0;
-                    if ((rc = timed_launch(h, s, [&] { return launch_voxelize_mapped(vm, std::min(per, b1 - m0), gauss, lane_range, s); }))) return rc;
+                    vg.p.b0 = m0;
+                    if ((rc = timed_launch(h, s, [&] { return launch_voxelize_grouped(vg, std::min(per, b1 - m0), gauss, lane_range, s); }))) return rc;
                 }
             }
             va.p.ncc = nfull;

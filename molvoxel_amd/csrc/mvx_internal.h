@@ -103,21 +103,19 @@ struct DirectArgs {
 };
 
 // Channel-wise radii for features (numpy/voxelizer.py:213-224: one membership test and one density per channel): channels
-// that share a radius share both. chan_aux_kernel sorts the C channels into at most CHAN_GROUP_SLOTS slots of at most 32
-// channels with one radius each; the mapped voxelize launch runs one workgroup per (slab, molecule, slot) with that
-// slot's threshold / coefficient for every candidate and its channel list for the weights and the stores. More distinct
-// radii than slots (or more than 32 x slots channels): `fallback` = 1, the mapped launch returns at once and the general
+// that share a radius share both. chan_aux_kernel numbers the distinct radii (slots, in order of first appearance) and
+// the grouped voxelize launch evaluates, per candidate pair, one threshold test and one exp2 per SLOT and feeds the
+// matrix cores the weight row masked to that slot's channels - d2, staging, culls and the stores are shared by all slots.
+// More than CHAN_GROUP_SLOTS distinct radii: `fallback` = 1, the grouped launch returns at once and the general
 // per-channel kernel (which returns at once otherwise) does the call.
-constexpr int CHAN_GROUP_SLOTS = 8;
-struct ChanGroupSlot {
-    double T;        // d2_threshold(radius)
-    float k;         // gauss_coeff(radius, sigma)
-    int32_t nch;
-    int32_t ch[32];  // channel of weight slot j, -1 beyond nch
-};
+constexpr int CHAN_GROUP_SLOTS = 32; // (one bit each in the chunk's slot mask)
 struct ChanGroups {
     int32_t nslots, fallback, pad[2];
-    ChanGroupSlot g[CHAN_GROUP_SLOTS];
+    struct {
+        double T;  // d2_threshold(radius)
+        float k;   // gauss_coeff(radius, sigma)
+        int32_t pad;
+    } slot[CHAN_GROUP_SLOTS];
 };
 
 struct VoxArgs {
@@ -135,8 +133,9 @@ struct VoxArgs {
 };
 
 // launchers (host side, mvx_kernels.hip)
+// chan_slot: C ints, the slot of every channel (grouped launch)
 hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax,
-                           double *Tc, float *kc, ChanGroups *groups, hipStream_t s);
+                           double *Tc, float *kc, ChanGroups *groups, int32_t *chan_slot, hipStream_t s);
 hipError_t launch_chan_aux64(const double *radii, int32_t C, int32_t density, double sigma, double *rmax, double *Tc, double *kc,
                              hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
@@ -148,8 +147,9 @@ hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf
 // ct: channels per thread (1, 4, 8, 16, 32); lane_range: per-lane index-range check needed
 // voxelize molecules [a.p.b0, a.p.b0 + nb): every slab, whatever its candidate count (line, line + extension, x-list)
 hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
-// channel-wise features, grouped by radius: a.Tc must point at the ChanGroups table (a.p.ncc = CHAN_GROUP_SLOTS, ct = 32)
-hipError_t launch_voxelize_mapped(const VoxArgs &a, int32_t nb, bool gauss, bool lane_range, hipStream_t s);
+// channel-wise features, grouped by radius: a.Tc must point at the ChanGroups table, a.kc at the channels' slots;
+// chunks of 32 channels (a.p.ncc = ceil(C / 32)), feature rows read in place
+hipError_t launch_voxelize_grouped(const VoxArgs &a, int32_t nb, bool gauss, bool lane_range, hipStream_t s);
 // float64 grids: every slab of the whole batch through the general slab loop (ct <= 16; a.p.dcap must be 64)
 hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
 // the whole call in one launch (float32 grids, NW <= 8): no workspace, no pre-pass

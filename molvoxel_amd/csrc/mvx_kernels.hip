@@ -235,41 +235,54 @@ __device__ __forceinline__ int find_molecule(const int64_t *offsets, int B, int6
 // ------------------------------------------------------------------------------------------------
 // channel-wise auxiliary: max radius (float32), per-channel thresholds / coefficients
 // ------------------------------------------------------------------------------------------------
-__global__ void chan_aux_kernel(const float *radii, int C, int density, float sigma32, float *rmax, double *Tc,
-                                float *kc, ChanGroups *groups) {
+__global__ void __launch_bounds__(256) chan_aux_kernel(const float *radii, int C, int density, float sigma32, float *rmax, double *Tc,
+                                                       float *kc, ChanGroups *groups, int *chan_slot) {
+    // slot of a channel = number of distinct radii (float32 bits) that appear before its radius' first appearance
+    constexpr int CMAX = 2048; // more channels: no grouping
+    __shared__ unsigned rb[CMAX];
+    __shared__ unsigned char is_first[CMAX];
+    __shared__ int over;
+    if (threadIdx.x == 0) over = 0;
+    const bool small = C <= CMAX;
+    for (int c = threadIdx.x; c < C && small; c += blockDim.x) rb[c] = __float_as_uint(radii[c]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C && small; c += blockDim.x) {
+        bool f = true;
+        for (int i = 0; i < c && f; ++i) f = rb[i] != rb[c];
+        is_first[c] = f ? 1 : 0;
+    }
+    __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const float r = radii[c];
         Tc[c] = d2_threshold(r);
         kc[c] = density == MVX_GAUSSIAN ? gauss_coeff(r, sigma32) : 0.0f;
+        if (small) {
+            int first = c;
+            for (int i = 0; i < c; ++i)
+                if (rb[i] == rb[c]) {
+                    first = i;
+                    break;
+                }
+            int slot = 0;
+            for (int i = 0; i < first; ++i) slot += is_first[i];
+            chan_slot[c] = slot < CHAN_GROUP_SLOTS ? slot : -1;
+            if (slot >= CHAN_GROUP_SLOTS) over = 1;
+            else if (first == c) {
+                groups->slot[slot].T = d2_threshold(r);
+                groups->slot[slot].k = density == MVX_GAUSSIAN ? gauss_coeff(r, sigma32) : 0.0f;
+                groups->slot[slot].pad = 0;
+            }
+        }
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
         float m = radii[0];
         for (int c = 1; c < C; ++c) m = radii[c] > m ? radii[c] : m;
         rmax[0] = m;
-        // channels with the same radius (same float32 bits) -> slots of at most 32 channels, in channel order
-        int nslots = 0, fallback = 0;
-        unsigned bits[CHAN_GROUP_SLOTS];
-        for (int c = 0; c < C && !fallback; ++c) {
-            const unsigned rb = __float_as_uint(radii[c]);
-            int slot = -1;
-            for (int g = 0; g < nslots; ++g)
-                if (bits[g] == rb && groups->g[g].nch < 32) slot = g;
-            if (slot < 0) {
-                if (nslots == CHAN_GROUP_SLOTS) {
-                    fallback = 1;
-                    break;
-                }
-                slot = nslots++;
-                bits[slot] = rb;
-                groups->g[slot].T = d2_threshold(radii[c]);
-                groups->g[slot].k = density == MVX_GAUSSIAN ? gauss_coeff(radii[c], sigma32) : 0.0f;
-                groups->g[slot].nch = 0;
-                for (int j = 0; j < 32; ++j) groups->g[slot].ch[j] = -1;
-            }
-            groups->g[slot].ch[groups->g[slot].nch++] = c;
-        }
-        groups->nslots = nslots;
-        groups->fallback = fallback;
+        int n = 0;
+        for (int c = 0; c < C && small; ++c) n += is_first[c];
+        groups->nslots = n;
+        groups->fallback = (!small || over) ? 1 : 0;
     }
 }
 
@@ -293,8 +306,8 @@ hipError_t launch_chan_aux64(const double *radii, int32_t C, int32_t density, do
 }
 
 hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax, double *Tc,
-                           float *kc, ChanGroups *groups, hipStream_t s) {
-    hipLaunchKernelGGL(chan_aux_kernel, dim3(1), dim3(256), 0, s, radii, C, density, sigma32, rmax, Tc, kc, groups);
+                           float *kc, ChanGroups *groups, int32_t *chan_slot, hipStream_t s) {
+    hipLaunchKernelGGL(chan_aux_kernel, dim3(1), dim3(256), 0, s, radii, C, density, sigma32, rmax, Tc, kc, groups, chan_slot);
     return hipGetLastError();
 }
 
@@ -943,10 +956,10 @@ size_t dense64_lds_bytes(int32_t ct, int32_t NW) {
 struct LaneCtx {
     double gx, gy, gz; // voxel centre: axis[i] = i*res - width/2 (numpy/voxelizer.py:41-43)
     double gx1;        // OpsMx32 only (two voxels per lane: (ix, iy, iz) and (ix + 1, iy, iz)): the second voxel's x
-    double Tg;         // mapped launches (channel-wise features grouped by radius) only: the slot's threshold, coefficient
-    float kg;          // ... and, for the lanes that stage channel weights, the feature column they read (-1: none)
-    int wcol;
-    const int *cmap;   // ... and the slot's channel list (LDS copy): channel of accumulator c, -1 = none
+    int grp;           // grouped launches (channel-wise features by radius) only: the radius slot of channel cbase + lane % 32
+                       // (-1: no such channel), the slots present in this chunk (bit mask, uniform) and the LDS copy of
+    unsigned gmask;    // the slots' {T, k}
+    const double *gtab;
     int ix, iy, iz;
     int zt_w;          // this wave's sub-tile index along z
     int cbase;         // first channel of this workgroup's chunk
@@ -1020,11 +1033,10 @@ __device__ __forceinline__ void accumulate_row(float2v (&acc)[(CT + 1) / 2], con
 
 // Write-out of one slab. `any` false: zero fill without the LDS round trip. Begins with a barrier (the union region
 // may still hold candidate rows) and ends without one.
-// MAPPED: accumulator c belongs to channel cmap[c] (-1: to none) instead of cbase + c
-template <int CT, int CRMAX = MVX_CR, bool MAPPED = false>
+template <int CT, int CRMAX = MVX_CR>
 __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], bool any, float *tile, int tid, int lane,
                                            int wave, int NW, int b, int cbase, int x0, int y0, int z0, float *out,
-                                           const VoxParams &P, const int *cmap = nullptr) {
+                                           const VoxParams &P) {
     constexpr int CR = CT < CRMAX ? CT : CRMAX; // channels per write-out round
     constexpr int NROUND = CT / CR;
     const int D = P.D;
@@ -1036,7 +1048,7 @@ __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], b
     const int zq = z0 + 4 * q;
     const int sxx = (rfirst >> SUBY_SH) & (SUBX - 1), syy = rfirst & (SUBY - 1), cfirst = rfirst / RPC;
     const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
-    float *dst0 = out + ((size_t)b * P.C + (MAPPED ? 0 : cbase + cfirst)) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
+    float *dst0 = out + ((size_t)b * P.C + cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
     if (!any) {
         // Pacing: a workgroup that has nothing to compute would fire its 64 KB of stores the moment it starts; holding
         // them back ~1.7 us (4096 cycles) lets the store streams of the resident workgroups interleave: ligand batches
@@ -1047,9 +1059,8 @@ __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], b
 #pragma unroll
             for (int p = 0; p < (CT + 3) / 4; ++p) {
                 const int c = cfirst + 4 * p;
-                const int mc = (MAPPED && c < CT) ? cmap[c] : 0;
-                if (c < CT && (MAPPED ? mc >= 0 : cbase + c < P.C)) {
-                    float *dst = dst0 + (size_t)(MAPPED ? mc : 4 * p) * D3;
+                if (c < CT && cbase + c < P.C) {
+                    float *dst = dst0 + (size_t)(4 * p) * D3;
                     if (P.vec_store) {
                         store_f4(dst, make_float4(0.f, 0.f, 0.f, 0.f), P.store_kind);
                     } else {
@@ -1080,10 +1091,9 @@ __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], b
 #pragma unroll
             for (int p = 0; p < (CR + 3) / 4; ++p) {
                 const int c = cfirst + 4 * p; // channel inside the round
-                const int mc = (MAPPED && c < CR) ? cmap[rd * CR + c] : 0;
-                if (c < CR && (MAPPED ? mc >= 0 : cbase + rd * CR + c < P.C)) {
+                if (c < CR && cbase + rd * CR + c < P.C) {
                     const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 4 * RPC * p) * RS + 4 * q);
-                    float *dst = dst0 + (size_t)(MAPPED ? mc : rd * CR + 4 * p) * D3;
+                    float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
                     if (P.vec_store) {
                         store_f4(dst, v, P.store_kind);
                     } else {
@@ -1206,10 +1216,10 @@ __device__ __forceinline__ void accumulate_row64(double (&acc)[CT], const unsign
 // What differs between float32 and float64 grids: accumulator type, staged row width, the per-candidate update
 // and the write-out. OpsF32 is the tuned path; OpsF64 favours exactness over speed (8-B stores straight from
 // registers, no LDS transposition).
-template <int CT_, bool GAUSS, bool CHANWISE, bool LANE_RANGE, bool MAPPED_ = false>
+template <int CT_, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
 struct OpsF32 {
     static constexpr int CT = CT_;
-    static constexpr bool MAPPED = MAPPED_;
+    static constexpr bool GROUPED = false;
     typedef float2v Acc[(CT + 1) / 2];
     static constexpr int WORDS = 1;                   // 32-bit words per channel weight
     static constexpr int WW = CT;                     // weight words staged per row
@@ -1236,8 +1246,8 @@ struct OpsF32 {
     }
     static __device__ __forceinline__ void write(const Acc &acc, bool any, unsigned *un, int tid, int lane, int wave, int NW,
                                                  int b, const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
-        write_slab<CT, MVX_CR, MAPPED>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
-                                       static_cast<float *>(out), P, MAPPED ? L.cmap : nullptr);
+        write_slab<CT>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
+                       static_cast<float *>(out), P);
     }
     // per-molecule launches (voxelize_direct_kernel): 16 channels per round - two rounds, four barriers; the small
     // rounds pay when thousands of workgroups' store bursts interleave, not when 512 workgroups store once (cfg-2
@@ -1275,10 +1285,10 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int MX_CR = 8; // channels per write-out round of the matrix-core path
 size_t voxelize_mx_lds_bytes(int32_t NW) { return voxelize_lds_bytes(32, NW, MX_CR); }
 
-template <bool GAUSS, bool LANE_RANGE, bool MAPPED_ = false>
+template <bool GAUSS, bool LANE_RANGE, bool GROUPED_ = false>
 struct OpsMx32 {
     static constexpr int CT = 32;
-    static constexpr bool MAPPED = MAPPED_;
+    static constexpr bool GROUPED = GROUPED_;
     struct Acc {
         f16v p0, p1; // the x0 plane and the x0 + 1 plane of the sub-tile
     };
@@ -1337,12 +1347,33 @@ struct OpsMx32 {
             } else {
                 k = __uint_as_float(r[8]);
             }
-            const float eva = GAUSS ? __builtin_amdgcn_exp2f(k * (float)d2a) : 1.0f;
-            const float evb = GAUSS ? __builtin_amdgcn_exp2f(k * (float)d2b) : 1.0f;
-            const float va = hita ? eva : 0.0f, vb = hitb ? evb : 0.0f;
             const float wj = valid ? __uint_as_float(r[16 + j]) : 0.0f;
-            acc.p0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wj, va, acc.p0, 0, 0, 0);
-            acc.p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wj, vb, acc.p1, 0, 0, 0);
+            if constexpr (GROUPED) {
+                // channel-wise radii: the record's radius is max(radii) (the culls' radius, numpy/voxelizer.py:138), so
+                // hita / hitb so far only say "inside the largest ball" (and the index ranges). Per radius slot present
+                // in this chunk: its own threshold and density for the same d2, the weight row masked to its channels -
+                // channels of other slots receive fma(0, val, acc) = acc.
+                const float d2fa = (float)d2a, d2fb = (float)d2b;
+                unsigned todo = L.gmask;
+                while (todo) {
+                    const int g = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    const double Tg = L.gtab[2 * g];
+                    const float kg = reinterpret_cast<const float *>(L.gtab + 2 * g + 1)[0];
+                    const float eva = GAUSS ? __builtin_amdgcn_exp2f(kg * d2fa) : 1.0f;
+                    const float evb = GAUSS ? __builtin_amdgcn_exp2f(kg * d2fb) : 1.0f;
+                    const float va = (hita && d2a <= Tg) ? eva : 0.0f, vb = (hitb && d2b <= Tg) ? evb : 0.0f;
+                    const float wg = L.grp == g ? wj : 0.0f;
+                    acc.p0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg, va, acc.p0, 0, 0, 0);
+                    acc.p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg, vb, acc.p1, 0, 0, 0);
+                }
+            } else {
+                const float eva = GAUSS ? __builtin_amdgcn_exp2f(k * (float)d2a) : 1.0f;
+                const float evb = GAUSS ? __builtin_amdgcn_exp2f(k * (float)d2b) : 1.0f;
+                const float va = hita ? eva : 0.0f, vb = hitb ? evb : 0.0f;
+                acc.p0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wj, va, acc.p0, 0, 0, 0);
+                acc.p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wj, vb, acc.p1, 0, 0, 0);
+            }
         }
     }
     static __device__ __forceinline__ void write(const Acc &acc, bool any, unsigned *un, int tid, int lane, int wave, int NW,
@@ -1350,8 +1381,7 @@ struct OpsMx32 {
         float *out = static_cast<float *>(out_);
         if (!any) { // zero fill without the LDS round trip: the one-voxel-per-lane code (no accumulator is read)
             float2v zero[16];
-            write_slab<32, MVX_CR, MAPPED>(zero, false, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0, out, P,
-                                           MAPPED ? L.cmap : nullptr);
+            write_slab<32>(zero, false, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0, out, P);
             return;
         }
         float *tile = reinterpret_cast<float *>(un);
@@ -1364,7 +1394,7 @@ struct OpsMx32 {
         const int q = tid % F4, rfirst = tid / F4, zq = z0 + 4 * q;
         const int sxx = (rfirst >> SUBY_SH) & (SUBX - 1), syy = rfirst & (SUBY - 1), cfirst = rfirst / RPC;
         const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
-        float *dst0 = out + ((size_t)b * P.C + (MAPPED ? 0 : L.cbase + cfirst)) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
+        float *dst0 = out + ((size_t)b * P.C + L.cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
         // this lane's voxel column in the tile, and the first of its four channels of a round
         const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1), h = lane >> 5;
         float *mine = tile + (4 * h * RPC + ly) * RS + SUBZ * wave + lz; // + (c * RPC + x * SUBY) * RS
@@ -1383,10 +1413,9 @@ struct OpsMx32 {
 #pragma unroll
                 for (int p = 0; p < (CR + 3) / 4; ++p) {
                     const int c = cfirst + 4 * p; // channel inside the round
-                    const int mc = (MAPPED && c < CR) ? L.cmap[rd * CR + c] : 0;
-                    if (c < CR && (MAPPED ? mc >= 0 : L.cbase + rd * CR + c < P.C)) {
+                    if (c < CR && L.cbase + rd * CR + c < P.C) {
                         const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 4 * RPC * p) * RS + 4 * q);
-                        float *dst = dst0 + (size_t)(MAPPED ? mc : rd * CR + 4 * p) * D3;
+                        float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
                         if (P.vec_store) {
                             store_f4(dst, v, P.store_kind);
                         } else {
@@ -1522,10 +1551,10 @@ __device__ __forceinline__ void line_round_scalar(const bool xl, typename Ops::A
     // round e0 / RW of the slab's candidates: row slot sl holds entry e0 + sl of the line (entries 1..n_line; entry e sits
     // at line[e] up to SLOTS-1 and at ext[e - SLOTS] beyond)
     constexpr int SW = Ops::SW;
-    // (mapped launches: the weight lanes read the feature columns of the slot's channel list)
-    const unsigned *src = lane < 16 ? rec + lane : w + (Ops::MAPPED ? (L.wcol < 0 ? 0 : L.wcol) : Ops::WORDS * L.cbase + lane - 16);
+    const unsigned *src = lane < 16 ? rec + lane : w + (Ops::WORDS * L.cbase + lane - 16);
     const size_t stride = lane < 16 ? (size_t)16 : (size_t)(Ops::WORDS * P.w_stride);
-    const bool stager = lane < 16 + Ops::WW;
+    // (grouped launches read the caller's feature rows in place whatever C is: no column beyond the row)
+    const bool stager = lane < 16 + Ops::WW && (!Ops::GROUPED || lane < 16 || L.cbase + lane - 16 < P.C);
     int ai[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) { // eight independent scalar loads
@@ -1539,20 +1568,10 @@ __device__ __forceinline__ void line_round_scalar(const bool xl, typename Ops::A
         v[u] = 0u;
         if (e >= 1 && e <= n_line && stager) v[u] = src[(size_t)(a0 + ai[u]) * stride];
     }
-    if (Ops::MAPPED) {
-        // the slot's radius instead of the record's (which holds max(radii): the culls' radius, numpy/voxelizer.py:138):
-        // words 6-7 of a row are T, word 8 is k; weight lanes beyond the slot's channels stage zeros
-        const unsigned long long tb = (unsigned long long)__double_as_longlong(L.Tg);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            v[u] = lane == 6 ? (unsigned)tb : (lane == 7 ? (unsigned)(tb >> 32) : (lane == 8 ? __float_as_uint(L.kg) : v[u]));
-            if (lane >= 16 && L.wcol < 0) v[u] = 0u;
-        }
-    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int sl = wave + u * NW, e = e0 + sl;
-        if (e >= 1 && e <= n_line && stager) un[sl * SW + lane] = v[u];
+        if (e >= 1 && e <= n_line && (stager || (Ops::GROUPED && lane < 16 + Ops::WW))) un[sl * SW + lane] = v[u]; // (v = 0 beyond C)
     }
     VK_STAMP(2);
     __syncthreads();
@@ -1576,25 +1595,30 @@ __device__ __forceinline__ void line_round_scalar(const bool xl, typename Ops::A
 }
 
 // voxelize_kernel's arithmetic: 32-channel chunks go to the matrix cores (OpsMx32), everything else to the vector ALU
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, bool MAPPED>
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, bool GROUPED>
 struct SlabOps {
-    typedef OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE, MAPPED> type;
+    typedef OpsF32<CT, GAUSS, CHANWISE, LANE_RANGE> type;
 };
 #ifndef MVX_NO_MX // (A/B builds)
 // (not the per-lane-range variants - blockdim 4, 5, 12, ...: their six extra index comparisons per voxel do not fit the
 // 64 registers of the two-voxel layout without scratch: 0.527 against 0.479 ms per 64 cfg-2 molecules at blockdim 5)
-template <bool GAUSS, bool MAPPED>
-struct SlabOps<32, GAUSS, false, false, MAPPED> {
-    typedef OpsMx32<GAUSS, false, MAPPED> type;
+template <bool GAUSS, bool GROUPED>
+struct SlabOps<32, GAUSS, false, false, GROUPED> {
+    typedef OpsMx32<GAUSS, false, GROUPED> type;
+};
+// (grouped launches - channel-wise features by radius - exist on the matrix-core path only, per-lane ranges or not)
+template <bool GAUSS>
+struct SlabOps<32, GAUSS, false, true, true> {
+    typedef OpsMx32<GAUSS, true, true> type;
 };
 #endif
 
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT, bool MAPPED = false>
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT, bool GROUPED = false>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     voxelize_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
                     const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
                     const VoxParams P) {
-    typedef typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE, MAPPED>::type Ops;
+    typedef typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE, GROUPED>::type Ops;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1614,9 +1638,9 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
         const ChanGroups *G = reinterpret_cast<const ChanGroups *>(reinterpret_cast<const char *>(Tc) - sizeof(ChanGroups));
         if (!G->fallback) return;
     }
-    const ChanGroups *__restrict__ G = reinterpret_cast<const ChanGroups *>(Tc); // (mapped launches only)
-    if constexpr (MAPPED) {
-        if (G->fallback || cc >= G->nslots) return; // (cc = the slot: P.ncc = CHAN_GROUP_SLOTS)
+    const ChanGroups *__restrict__ G = reinterpret_cast<const ChanGroups *>(Tc); // (grouped launches only)
+    if constexpr (GROUPED) {
+        if (G->fallback) return;
     }
     // the slab's candidate line: {count, first atom}, then {atom index, packed ranges} per candidate
     const uint2 *__restrict__ line = slist + ((size_t)b * (size_t)gridDim.x + t) * SLOTS; // (uniform: scalar loads)
@@ -1624,15 +1648,20 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     int sx, sy, zc;
     decode_slab(t, P, sx, sy, zc);
     const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
-    LaneCtx L = Ops::ctx(lane, wave, x0, y0, z0, zc * NW, MAPPED ? 0 : P.c0 + cc * CT, P);
-    if constexpr (MAPPED) {
-        int *cmap = reinterpret_cast<int *>(smem + P.dcap); // (P.dcap: bytes of the rows / tile region in mapped launches)
-        if (tid < 32) cmap[tid] = G->g[cc].ch[tid];
-        L.cmap = cmap;
-        L.Tg = G->g[cc].T;
-        L.kg = G->g[cc].k;
-        L.wcol = (lane >= 16 && lane < 48) ? G->g[cc].ch[lane - 16] : 0;
-        __syncthreads(); // (the list is read in the write-out, which an empty slab reaches without another barrier)
+    LaneCtx L = Ops::ctx(lane, wave, x0, y0, z0, zc * NW, P.c0 + cc * CT, P);
+    if constexpr (GROUPED) {
+        // the radius slot of this lane's channel, the slots present in the chunk, {T, k} of every slot in LDS
+        const int *chan_slot = reinterpret_cast<const int *>(kc);
+        const int ch = L.cbase + (lane & 31);
+        L.grp = ch < P.C ? chan_slot[ch] : -1;
+        unsigned present = 0;
+#pragma unroll
+        for (int g = 0; g < CHAN_GROUP_SLOTS; ++g) present |= (__ballot(L.grp == g) != 0ull) ? (1u << g) : 0u; // (uniform)
+        L.gmask = present;
+        double *gtab = reinterpret_cast<double *>(smem + P.dcap); // (P.dcap: bytes of the rows / tile region in grouped launches)
+        if (tid < 2 * CHAN_GROUP_SLOTS) gtab[tid] = reinterpret_cast<const double *>(&G->slot[0])[tid];
+        L.gtab = gtab;
+        // (published by the staging barrier, which every walk sits behind)
     }
 
     typename Ops::Acc acc;
@@ -2353,7 +2382,7 @@ static hipError_t launch_dense(const VoxArgs &a, size_t lds, unsigned grid, unsi
     return hipGetLastError();
 }
 
-struct MappedFn {
+struct GroupedFn {
     const VoxArgs &a;
     int32_t nb;
     hipStream_t s;
@@ -2366,13 +2395,12 @@ struct MappedFn {
             if (nb <= 0) return hipSuccess;
             if ((long long)nb * p.ncc > 65535) return hipErrorInvalidConfiguration;
             static LdsLimit raised;
-            const bool mx = std::is_same<typename SlabOps<CT, GAUSS, false, LANE_RANGE, true>::type, OpsMx32<GAUSS, LANE_RANGE, true>>::value;
-            const size_t main_lds = mx ? voxelize_mx_lds_bytes(p.NW) : voxelize_lds_bytes(CT, p.NW, MVX_CR);
-            p.dcap = (int32_t)main_lds; // where the slot's channel list sits in LDS
+            const size_t main_lds = voxelize_mx_lds_bytes(p.NW);
+            p.dcap = (int32_t)main_lds; // where the slots' {T, k} table sits in LDS
             auto kern = &voxelize_kernel<CT, GAUSS, false, LANE_RANGE, MAXT, true>;
-            hipError_t e = raise_lds_limit(kern, main_lds + 128, raised);
+            hipError_t e = raise_lds_limit(kern, main_lds + 16 * CHAN_GROUP_SLOTS, raised);
             if (e != hipSuccess) return e;
-            launch_profiled(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), main_lds + 128, s, a.rec, a.w,
+            launch_profiled(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), main_lds + 16 * CHAN_GROUP_SLOTS, s, a.rec, a.w,
                             a.slist, a.slist_ext, a.Tc, a.kc, static_cast<float *>(a.out), p);
             return hipGetLastError();
         }
@@ -2462,9 +2490,9 @@ hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss,
     return for_kernel(k, LaunchFn{a, nb, s});
 }
 
-hipError_t launch_voxelize_mapped(const VoxArgs &a, int32_t nb, bool gauss, bool lane_range, hipStream_t s) {
+hipError_t launch_voxelize_grouped(const VoxArgs &a, int32_t nb, bool gauss, bool lane_range, hipStream_t s) {
     KernelKey k{32, gauss, false, lane_range, a.p.NW <= 8 ? 512 : 1024};
-    return for_kernel(k, MappedFn{a, nb, s});
+    return for_kernel(k, GroupedFn{a, nb, s});
 }
 
 hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {

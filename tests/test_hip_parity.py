@@ -876,14 +876,15 @@ def test_overlapped_prepass_equals_serial_calls(mv):
 
 
 @pytest.mark.parametrize("C_,distinct,D,blockdim", [(32, 4, 32, None), (40, 2, 32, None), (12, 9, 24, None), (32, 1, 32, None),
-                                                    (7, 3, 27, 5), (64, 8, 16, None), (33, 33, 16, None)])
+                                                    (7, 3, 27, 5), (64, 8, 16, None), (33, 33, 16, None), (32, 32, 24, None),
+                                                    (70, 31, 16, None)])
 @pytest.mark.parametrize("density", ["gaussian", "binary"])
 def test_channel_wise_features_grouped_by_radius(mv, C_, distinct, D, blockdim, density):
     """Channel-wise radii for features (numpy/voxelizer.py:213-224): channels that share a radius share the membership test
-    and the density. The batched pipeline sorts the channels into at most 8 slots of at most 32 channels by radius on
-    the device and runs one workgroup per (slab, molecule, slot); radii that do not fit (9 distinct values, 33 distinct
-    values) fall back to the per-channel kernel. Every shape against the oracle, batched (grouped) against per-molecule
-    (direct kernel, per-channel), and a 40-channel group that spans two slots."""
+    and the density. The batched pipeline numbers the distinct radii on the device (up to 32 slots) and evaluates one
+    threshold test and one density per slot and candidate on the matrix-core path; more distinct radii (33 here) fall
+    back to the per-channel kernel. Every shape against the oracle, and batched (grouped) against per-molecule calls
+    (direct kernel, per-channel) bit for bit; chunks of 32 channels that hold several slots, slots that span chunks."""
     from oracle import c_oracle
 
     rng = np.random.default_rng(1000 * C_ + distinct)
