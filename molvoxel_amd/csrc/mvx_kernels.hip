@@ -922,6 +922,16 @@ size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t crmax) {
     const size_t cand = (size_t)64 * cand_stride_words(ct) * 4;
     return tile > cand ? tile : cand;
 }
+// voxelize_kernel's row / tile region (-DMVX_PREFETCH: two row buffers, the second one receives the next round's rows by LDS-DMA)
+size_t voxelize_rounds_lds_bytes(int32_t ct, int32_t NW, int32_t crmax) {
+    const size_t one = voxelize_lds_bytes(ct, NW, crmax);
+#ifdef MVX_PREFETCH
+    const size_t rows2 = (size_t)2 * 64 * cand_stride_words(ct) * 4;
+    return one > rows2 ? one : rows2;
+#else
+    return one;
+#endif
+}
 
 // dense kernel: candidate rows staged per round = what fits in the out tile's bytes, at least 64, at most LCAP
 int32_t voxelize_dcap(int32_t ct, int32_t NW) {
@@ -1283,7 +1293,7 @@ struct OpsF32 {
 // lanes 32-63, so every lane writes 4 channels x 2 planes per round) and its read-back / store code unchanged.
 typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int MX_CR = 8; // channels per write-out round of the matrix-core path
-size_t voxelize_mx_lds_bytes(int32_t NW) { return voxelize_lds_bytes(32, NW, MX_CR); }
+size_t voxelize_mx_lds_bytes(int32_t NW) { return voxelize_rounds_lds_bytes(32, NW, MX_CR); }
 
 template <bool GAUSS, bool LANE_RANGE, bool GROUPED_ = false>
 struct OpsMx32 {
@@ -1543,18 +1553,31 @@ __device__ __forceinline__ bool reaches_subtile(const unsigned *r, int lane, con
 // xl (workgroup-uniform, rare): the entries come from a (molecule, x-slab) list instead of a slab line (LINE_OVERFLOW slabs,
 // below): they have not been filtered against the slab's y rows, so the walk's row filter also tests the record's admitted
 // y range.
+// --- the rounds of voxelize_kernel: row slot sl of a round that starts at entry e0 holds entry e0 + sl of the line (entries
+// 1..n_line; entry e sits at line[e] up to SLOTS-1 and at ext[e - SLOTS] beyond; lanes 0-15 of a row are the record, lanes
+// 16.. the channel weights of the chunk) ---
 template <typename Ops>
-__device__ __forceinline__ void line_round_scalar(const bool xl, typename Ops::Acc &acc, const uint2 *__restrict__ line, const uint2 *__restrict__ ext,
-                                                  int e0, int n_line, int RW, unsigned *un, const unsigned *__restrict__ rec,
-                                                  const unsigned *__restrict__ w, int64_t a0, int lane, int wave, int NW, const LaneCtx &L,
-                                                  const VoxParams &P, const double *__restrict__ Tc, const float *__restrict__ kc) {
-    // round e0 / RW of the slab's candidates: row slot sl holds entry e0 + sl of the line (entries 1..n_line; entry e sits
-    // at line[e] up to SLOTS-1 and at ext[e - SLOTS] beyond)
-    constexpr int SW = Ops::SW;
-    const unsigned *src = lane < 16 ? rec + lane : w + (Ops::WORDS * L.cbase + lane - 16);
-    const size_t stride = lane < 16 ? (size_t)16 : (size_t)(Ops::WORDS * P.w_stride);
+struct RoundSrc {
+    const unsigned *src; // this lane's word of row 0 (record word / weight column)
+    size_t stride;       // words between the rows of consecutive atoms, for this lane
+    bool stager;         // this lane takes part in staging
+};
+template <typename Ops>
+__device__ __forceinline__ RoundSrc<Ops> round_src(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, int lane,
+                                                   const LaneCtx &L, const VoxParams &P) {
+    RoundSrc<Ops> R;
+    R.src = lane < 16 ? rec + lane : w + (Ops::WORDS * L.cbase + lane - 16);
+    R.stride = lane < 16 ? (size_t)16 : (size_t)(Ops::WORDS * P.w_stride);
     // (grouped launches read the caller's feature rows in place whatever C is: no column beyond the row)
-    const bool stager = lane < 16 + Ops::WW && (!Ops::GROUPED || lane < 16 || L.cbase + lane - 16 < P.C);
+    R.stager = lane < 16 + Ops::WW && (!Ops::GROUPED || lane < 16 || L.cbase + lane - 16 < P.C);
+    return R;
+}
+
+// Stage a round through registers: eight scalar loads of atom indices, eight row loads in flight, eight LDS writes.
+template <typename Ops>
+__device__ __forceinline__ void stage_round(const uint2 *__restrict__ line, const uint2 *__restrict__ ext, int e0, int n_line,
+                                            unsigned *un, const RoundSrc<Ops> &R, int64_t a0, int lane, int wave, int NW) {
+    constexpr int SW = Ops::SW;
     int ai[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) { // eight independent scalar loads
@@ -1566,16 +1589,58 @@ __device__ __forceinline__ void line_round_scalar(const bool xl, typename Ops::A
     for (int u = 0; u < 8; ++u) {
         const int e = e0 + wave + u * NW;
         v[u] = 0u;
-        if (e >= 1 && e <= n_line && stager) v[u] = src[(size_t)(a0 + ai[u]) * stride];
+        if (e >= 1 && e <= n_line && R.stager) v[u] = R.src[(size_t)(a0 + ai[u]) * R.stride];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int sl = wave + u * NW, e = e0 + sl;
-        if (e >= 1 && e <= n_line && (stager || (Ops::GROUPED && lane < 16 + Ops::WW))) un[sl * SW + lane] = v[u]; // (v = 0 beyond C)
+        if (e >= 1 && e <= n_line && (R.stager || (Ops::GROUPED && lane < 16 + Ops::WW))) un[sl * SW + lane] = v[u]; // (v = 0 beyond C)
     }
-    VK_STAMP(2);
-    __syncthreads();
-    VK_STAMP(3);
+}
+
+// The same rows by LDS-DMA (global_load_lds_dword: destination = wave-uniform row base + 4 * lane, no data registers):
+// issued for round r + 1 BEFORE round r is walked, into the other row buffer, so that a dense slab's further rounds find
+// their rows in LDS when the walk before them ends (phase timeline at a 2.0 A radius: a staging phase waits ~9 000 cycles
+// for its row loads behind the resident workgroups' stores, as long as a walk takes). Waited for by the vmcnt(0) that
+// __syncthreads() carries. (Weight lanes beyond C of a grouped launch are left as they are: their slot mask is empty.)
+template <typename Ops>
+__device__ __forceinline__ void prefetch_round(const uint2 *__restrict__ line, const uint2 *__restrict__ ext, int e0, int n_line,
+                                               unsigned *un, const RoundSrc<Ops> &R, int64_t a0, int wave, int NW) {
+    constexpr int SW = Ops::SW;
+    typedef const void __attribute__((address_space(1))) *gptr_t;
+    typedef void __attribute__((address_space(3))) *lptr_t;
+    // The atom indices through the scalar path, by hand: once an LDS-DMA (a store, to the compiler) has been issued in
+    // the loop, hipcc no longer treats the line as invariant and fetches these entries with global_load_dword - through
+    // the vector memory pipeline, behind the stores, one exposed latency per row. (s_load by asm is outside hipcc's
+    // s_waitcnt bookkeeping: the wait is part of the statement that hands the values over.)
+    int ai[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = e0 + wave + u * NW;
+        const bool in = e >= 1 && e <= n_line;
+        const uint2 *at = in ? (e < SLOTS ? line + e : ext + (e - SLOTS)) : line;
+        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(ai[u]) : "s"(at) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+s"(ai[0]), "+s"(ai[1]), "+s"(ai[2]), "+s"(ai[3]), "+s"(ai[4]), "+s"(ai[5]), "+s"(ai[6]), "+s"(ai[7])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int sl = wave + u * NW, e = e0 + sl;
+        if (e >= 1 && e <= n_line && R.stager)
+            __builtin_amdgcn_global_load_lds((gptr_t)(R.src + (size_t)(a0 + ai[u]) * R.stride), (lptr_t)(un + sl * SW), 4, 0, 0);
+    }
+}
+
+// One lane per staged row decides whether this wave walks it; then the walk. xl (workgroup-uniform, rare): the entries
+// come from a (molecule, x-slab) list instead of a slab line (LINE_OVERFLOW slabs, below): they have not been filtered
+// against the slab's y rows, so the row filter also tests the record's admitted y range.
+template <typename Ops>
+__device__ __forceinline__ void filter_walk(const bool xl, typename Ops::Acc &acc, int e0, int n_line, int RW, const unsigned *un,
+                                            int lane, int wave, const LaneCtx &L, const VoxParams &P, const double *__restrict__ Tc,
+                                            const float *__restrict__ kc) {
+    constexpr int SW = Ops::SW;
     bool ok = false;
     if (lane < RW && e0 + lane >= 1 && e0 + lane <= n_line) {
         const unsigned *r = un + lane * SW;
@@ -1702,11 +1767,38 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
         }
         // (the first round is peeled: it is staged before the accumulators exist - with 32 accumulators live across the
         // staging loads the kernel needs 90 VGPRs instead of 62 - and the normal case is this one round)
-        line_round_scalar<Ops>(xl, acc, line, ext, 0, n, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
+        const RoundSrc<Ops> RS_ = round_src<Ops>(rec, w, lane, L, P);
+        stage_round<Ops>(line, ext, 0, n, un, RS_, a0, lane, wave, NW);
+        VK_STAMP(2);
+        __syncthreads();
+        VK_STAMP(3);
+#ifndef MVX_PREFETCH
+        // every further round is staged through registers after the walk before it. (-DMVX_PREFETCH, measured and not
+        // used: the next round's rows by LDS-DMA into a second row buffer while this round is walked - correct, and
+        // slower at every radius: 0.75 / 0.62 / 0.48 of peak at 1.0 / 1.5 / 2.0 A against 0.78 / 0.64 / 0.49; what a
+        // compute unit's four workgroups queue on is the vector memory pipeline as a whole, and 27 KB of LDS instead of
+        // 18 KB per workgroup costs more than the hidden latency buys.)
+        filter_walk<Ops>(xl, acc, 0, n, RW, un, lane, wave, L, P, Tc, kc);
         for (int e0 = RW; e0 <= n; e0 += RW) {
             __syncthreads(); // every wave is done with the previous round's rows
-            line_round_scalar<Ops>(xl, acc, line, ext, e0, n, RW, un, rec, w, a0, lane, wave, NW, L, P, Tc, kc);
+            stage_round<Ops>(line, ext, e0, n, un, RS_, a0, lane, wave, NW);
+            __syncthreads();
+            filter_walk<Ops>(xl, acc, e0, n, RW, un, lane, wave, L, P, Tc, kc);
         }
+#else
+        // two row buffers: round r is walked from buffer r % 2 while the rows of round r + 1 arrive in the other one
+        unsigned *buf = un, *other = un + 64 * Ops::SW;
+        for (int e0 = 0;; e0 += RW) {
+            const bool more = e0 + RW <= n; // (uniform)
+            if (more) prefetch_round<Ops>(line, ext, e0 + RW, n, other, RS_, a0, wave, NW);
+            filter_walk<Ops>(xl, acc, e0, n, RW, buf, lane, wave, L, P, Tc, kc);
+            if (!more) break;
+            __syncthreads(); // this wave's DMA has landed (vmcnt(0)); everyone's has, and everyone is done with `buf`
+            unsigned *t = buf;
+            buf = other;
+            other = t;
+        }
+#endif
     }
     Ops::write(acc, n_hdr > 0, un, tid, lane, wave, NW, b, L, x0, y0, z0, out, P);
     VK_STAMP(6); // all stores issued
@@ -2418,7 +2510,7 @@ struct LaunchFn {
         if ((long long)nb * p.ncc > 65535) return hipErrorInvalidConfiguration;
         static LdsLimit raised;
         const bool mx = std::is_same<typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE, false>::type, OpsMx32<GAUSS, LANE_RANGE, false>>::value;
-        const size_t lds = mx ? voxelize_mx_lds_bytes(p.NW) : voxelize_lds_bytes(CT, p.NW, MVX_CR);
+        const size_t lds = mx ? voxelize_mx_lds_bytes(p.NW) : voxelize_rounds_lds_bytes(CT, p.NW, MVX_CR);
         auto kern = &voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>;
         hipError_t e = raise_lds_limit(kern, lds, raised);
         if (e != hipSuccess) return e;
