@@ -397,9 +397,12 @@ int run(mvx_handle *h, const RunArgs &r) {
     // cfg-2; the binary kernel has no exp to save and is faster as it was (4.1 against 3.5 TB/s). Measured and not used:
     // 32 channels on 8-wave slabs (one workgroup per unit: 3.05 / 2.7 TB/s), 16 channels squeezed into 80 VGPRs for
     // three 8-wave workgroups (26 dwords of scratch in the walk: 2.5 TB/s).
-    const bool wide64 = f64 && h->cfg.density == MVX_GAUSSIAN && r.C > 16 && h->max_ct64 >= 32 && h->max_ct >= 32 && h->force_nw == 0;
-    const SlabPlan sp = plan_slabs(h, wide64 ? 4 : 8);
-    const int ct = pick_ct(std::min(r.C, f64 ? (wide64 ? 32 : std::min(h->max_ct, h->max_ct64 >= 32 && sp.NW <= 8 && h->force_nw ? 32 : 16)) : h->max_ct));
+    // Round 3: more than 16 channels with scalar / atom-wise radii take chunks of 32 on 8-wave slabs through the
+    // matrix-core slab kernel (voxelize64_kernel, 128 registers, two workgroups per unit): a.p.dcap == 0 selects it.
+    const bool mx64 = f64 && r.C > 16 && !(r.radii_type == MVX_RADII_CHANNEL && r.mode == MODE_FEATURES) && h->max_ct64 >= 32 &&
+                      h->max_ct >= 32 && h->force_nw == 0;
+    const SlabPlan sp = plan_slabs(h, 8);
+    const int ct = pick_ct(std::min(r.C, f64 ? (mx64 ? 32 : std::min(h->max_ct, 16)) : h->max_ct));
     const int ncc = (r.C + ct - 1) / ct;
     // One launch for the whole call (voxelize_direct_kernel) when the per-workgroup atom scan is cheap next to the
     // slab's stores: per-molecule forward() calls, and batches of small molecules. Bigger jobs amortise the binning
@@ -594,7 +597,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.c0 = 0;
     va.p.NW = sp.NW;
     va.p.w_stride = Cpad;
-    va.p.dcap = f64 ? 64 : voxelize_dcap(ct, sp.NW);
+    va.p.dcap = f64 ? (mx64 ? 0 : 64) : voxelize_dcap(ct, sp.NW);
     // 16-B stores need whole float4 groups per row (D % 4 == 0) and a 16-B aligned grid; anything else (odd
     // dimensions, a slice `grid[i]` of a batch grid whose slices are not 16-B multiples) takes the scalar-store path
     va.p.vec_store = (D % (f64 ? 2 : 4) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) ? 1 : 0;

@@ -965,7 +965,8 @@ size_t dense64_lds_bytes(int32_t ct, int32_t NW) {
 // what a lane knows about its voxel and its workgroup's slab
 struct LaneCtx {
     double gx, gy, gz; // voxel centre: axis[i] = i*res - width/2 (numpy/voxelizer.py:41-43)
-    double gx1;        // OpsMx32 only (two voxels per lane: (ix, iy, iz) and (ix + 1, iy, iz)): the second voxel's x
+    double gx1;        // OpsMx32 / OpsMx64 (several voxels per lane): the x + 1 plane's coordinate
+    double gy1;        // OpsMx64 only (four voxels per lane: x, x + 1 times iy, iy + 2): the second y row's coordinate
     int grp;           // grouped launches (channel-wise features by radius) only: the radius slot of channel cbase + lane % 32
                        // (-1: no such channel), the slots present in this chunk (bit mask, uniform) and the LDS copy of
     unsigned gmask;    // the slots' {T, k}
@@ -1440,6 +1441,166 @@ struct OpsMx32 {
     }
 };
 
+// ---- float64 grids, 32 channels, on the matrix cores ---------------------------------------------------------------------
+// The same idea as OpsMx32 with v_mfma_f64_16x16x4_f64: D(16 x 16) += A(16 x 4) B(4 x 16), float64, the four k steps
+// accumulated in sequence with one rounding each (tools/micro/mfma64_layout.hip) - bit for bit the chain of fma in
+// candidate order of accumulate_row64. Operands one double per lane: A[i = lane % 16][k = lane / 16], B[k][j = lane % 16];
+// D[i = 4 r + lane / 16][j = lane % 16] in register r = 0..3. Per FOUR candidates (k = lane / 16 picks the lane's
+// candidate): lane l evaluates its candidate for four voxels - (x0 | x0 + 1, y0 + ly | y0 + 2 + ly, z) with (ly, lz) =
+// ((l % 16) / 8, l % 8): dx^2 and dy^2 each shared by two of them, dz^2 by all four - and the 64 voxels x 32 channels take
+// eight MFMAs (4 voxel blocks x 2 channel blocks, A = 16 channel weights of the candidate, B = the block's values).
+// The vector path spent 32 float64 FMAs (128 issue cycles) and sixteen 16-byte LDS reads per candidate and wave on this.
+typedef double d4v __attribute__((ext_vector_type(4)));
+constexpr int MX64_SW = 84; // 16 + 64 words, padded to an odd number of 16-B quads (one row per lane in the row filter)
+size_t voxelize_mx64_lds_bytes(int32_t NW) {
+    const size_t rows = (size_t)64 * MX64_SW * 4;
+    const size_t tile = (size_t)CR64 * RPC * row_stride_doubles(NW) * 8;
+    return rows > tile ? rows : tile;
+}
+
+template <bool GAUSS, bool LANE_RANGE>
+struct OpsMx64 {
+    static constexpr int CT = 32;
+    static constexpr bool GROUPED = false;
+    struct Acc {
+        d4v a[2][4]; // [channel block of 16][voxel block m = 2 x + yh]: channels 16 cb + 4 r + lane / 16, r = 0..3
+    };
+    static constexpr int WORDS = 2;
+    static constexpr int WW = 64;
+    static constexpr int SW = MX64_SW;
+    static __device__ __forceinline__ void zero(Acc &acc) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc.a[cb][m] = (d4v){0.0, 0.0, 0.0, 0.0};
+    }
+    static __device__ __forceinline__ LaneCtx ctx(int lane, int wave, int x0, int y0, int z0, int zt_lo, int cbase, const VoxParams &P) {
+        const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & 1;
+        LaneCtx L;
+        L.ix = x0;
+        L.iy = y0 + ly;
+        L.iz = z0 + SUBZ * wave + lz;
+        L.gx = (double)L.ix * P.res - P.half;
+        L.gx1 = (double)(L.ix + 1) * P.res - P.half;
+        L.gy = (double)L.iy * P.res - P.half;
+        L.gy1 = (double)(L.iy + 2) * P.res - P.half;
+        L.gz = (double)L.iz * P.res - P.half;
+        L.zt_w = zt_lo + wave;
+        L.cbase = cbase;
+        return L;
+    }
+    static __device__ __forceinline__ void walk(Acc &acc, unsigned long long mask, const unsigned *un, int lane, const LaneCtx &L,
+                                                const VoxParams &P, const double *__restrict__, const float *__restrict__) {
+        const int q = lane >> 4; // which candidate of the four this lane evaluates
+        const int j = lane & 15; // ... and which of its 16-channel blocks' weights it feeds
+        while (mask) {
+            // up to four rows, in order (uniform)
+            int s[4];
+            int have = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[k] = 0;
+                if (mask) {
+                    s[k] = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    have = k + 1;
+                }
+            }
+            const bool valid = q < have; // a short last group: the missing candidates add fma(0, 0, acc) = acc
+            const int sq = q == 0 ? s[0] : (q == 1 ? s[1] : (q == 2 ? s[2] : s[3]));
+            const unsigned *r = un + sq * SW;
+            const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
+            const double2 PzT = *reinterpret_cast<const double2 *>(r + 4); // pz, T
+            const double dx0 = Pxy.x - L.gx, dx1 = Pxy.x - L.gx1, dy0 = Pxy.y - L.gy, dy1 = Pxy.y - L.gy1, dz = PzT.x - L.gz;
+            const double sx0 = dx0 * dx0, sx1 = dx1 * dx1, sy0 = dy0 * dy0, sy1 = dy1 * dy1, sz = dz * dz;
+            double d2[4]; // m = 2 x + yh; cdist order (dx^2 + dy^2) + dz^2, no fma
+            d2[0] = (sx0 + sy0) + sz;
+            d2[1] = (sx0 + sy1) + sz;
+            d2[2] = (sx1 + sy0) + sz;
+            d2[3] = (sx1 + sy1) + sz;
+            bool hit[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) hit[m] = valid && d2[m] <= PzT.y;
+            if (LANE_RANGE) {
+                const uint4 rg = *reinterpret_cast<const uint4 *>(r + 8); // k, type, xr, yr
+                const unsigned zr = r[12];
+                const bool zok = (L.iz >= (int)(zr & 0xffff)) && (L.iz <= (int)(zr >> 16));
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int ix = L.ix + (m >> 1), iy = L.iy + 2 * (m & 1);
+                    hit[m] = hit[m] && zok && (ix >= (int)(rg.z & 0xffff)) && (ix <= (int)(rg.z >> 16)) && (iy >= (int)(rg.w & 0xffff)) &&
+                             (iy <= (int)(rg.w >> 16));
+                }
+            }
+            double val[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) val[m] = hit[m] ? 1.0 : 0.0;
+            if (GAUSS) {
+                const double c64 = *reinterpret_cast<const double *>(r + 14);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    if (__ballot(hit[m]) != 0ull) { // (wave-uniform: exp is ~45 float64 instructions)
+                        const double e = exp(c64 * d2[m]);
+                        val[m] = hit[m] ? e : 0.0;
+                    }
+            }
+            const double w0 = valid ? *reinterpret_cast<const double *>(r + 16 + 2 * j) : 0.0;        // channel j of the row
+            const double w1 = valid ? *reinterpret_cast<const double *>(r + 16 + 2 * (16 + j)) : 0.0; // channel 16 + j
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc.a[0][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, val[m], acc.a[0][m], 0, 0, 0);
+                acc.a[1][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, val[m], acc.a[1][m], 0, 0, 0);
+            }
+        }
+    }
+    // Write-out through the float64 tile of write_slab64 ([channel][x, y row][z], CR64 = 8 channels per round). Round t
+    // holds channels 8 t .. 8 t + 7 = channel block t / 2, i = 8 (t % 2) + 4 rr + lane / 16 with rr = 0, 1, i.e. registers
+    // r = 2 (t % 2) + rr of every lane: each lane writes 2 channels x 4 voxels per round.
+    static __device__ __forceinline__ void write(const Acc &acc, bool, unsigned *un, int tid, int lane, int wave, int NW, int b,
+                                                 const LaneCtx &L, int x0, int y0, int z0, void *out_, const VoxParams &P) {
+        double *out = static_cast<double *>(out_);
+        double *tile = reinterpret_cast<double *>(un);
+        constexpr int CR = CR64, NROUND = 32 / CR;
+        const int D = P.D;
+        const int RS = row_stride_doubles(NW);
+        const size_t D2 = (size_t)D * D, D3 = D2 * D;
+        const int F2 = (SUBZ / 2) * NW; // 16-B slots per row
+        const int nthr = NW * 64;
+        const int rows_per_pass = nthr / F2; // 16 for any NW
+        const int qq = tid % F2, rfirst = tid / F2;
+        const int zq = z0 + 2 * qq;
+        const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & 1, q = lane >> 4;
+        const bool vec = P.vec_store != 0; // D even and a 16-B aligned grid
+        double *mine = tile + (q * RPC + ly) * RS + SUBZ * wave + lz; // + (4 rr * RPC + x * SUBY + 2 yh) * RS
+#pragma unroll
+        for (int t = 0; t < NROUND; ++t) {
+            __syncthreads(); // candidate rows (round 0) / previous tile (later rounds) fully consumed
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    mine[(4 * rr * RPC + (m >> 1) * SUBY + 2 * (m & 1)) * RS] = acc.a[t / 2][m][2 * (t % 2) + rr];
+            __syncthreads();
+            for (int row = rfirst; row < CR * RPC; row += rows_per_pass) {
+                const int c = row / RPC, rw = row - c * RPC;
+                const int sxx = (rw >> SUBY_SH) & (SUBX - 1), syy = rw & (SUBY - 1);
+                const int ch = L.cbase + t * CR + c;
+                if (ch < P.C && x0 + sxx < D && y0 + syy < D && zq < D) {
+                    const double2 v = *reinterpret_cast<const double2 *>(tile + row * RS + 2 * qq);
+                    double *dst = out + ((size_t)b * P.C + ch) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
+                    if (vec) {
+                        typedef double d2v __attribute__((ext_vector_type(2)));
+                        __builtin_nontemporal_store((d2v){v.x, v.y}, reinterpret_cast<d2v *>(dst));
+                    } else {
+                        dst[0] = v.x;
+                        if (zq + 1 < D) dst[1] = v.y;
+                    }
+                }
+            }
+        }
+    }
+};
+
 template <int CT_, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
 struct OpsF64 {
     static constexpr int CT = CT_;
@@ -1528,7 +1689,7 @@ __device__ __forceinline__ bool reaches_subtile(const unsigned *r, int lane, con
     // this lane's voxel is (lx, ly, lz) inside the sub-tile: the box centre is the same for every lane
     // (lx: lanes 32..63 hold the x + 1 plane in the one-voxel-per-lane layout; in the two-voxel layout every lane's gx is
     // the x plane's and the upper half of the wave holds other candidates, not other voxels: L.ix tells which)
-    const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1), lx = L.ix & (SUBX - 1);
+    const int lz = L.iz & (SUBZ - 1), ly = L.iy & (SUBY - 1), lx = L.ix & (SUBX - 1); // (sub-tile origins are multiples of its edges)
     const float cx = (float)L.gx + (0.5f * (SUBX - 1) - (float)lx) * res;
     const float cy = (float)L.gy + (0.5f * (SUBY - 1) - (float)ly) * res;
     const float cz = (float)L.gz + (0.5f * (SUBZ - 1) - (float)lz) * res;
@@ -1561,7 +1722,11 @@ struct RoundSrc {
     const unsigned *src; // this lane's word of row 0 (record word / weight column)
     size_t stride;       // words between the rows of consecutive atoms, for this lane
     bool stager;         // this lane takes part in staging
+    const unsigned *src2; // rows wider than a wave (float64, 32 channels: 16 + 64 words): lanes 0.. fetch words 64.. too
+    size_t stride2;
 };
+template <typename Ops>
+constexpr int round_tail() { return 16 + Ops::WW > 64 ? 16 + Ops::WW - 64 : 0; }
 template <typename Ops>
 __device__ __forceinline__ RoundSrc<Ops> round_src(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, int lane,
                                                    const LaneCtx &L, const VoxParams &P) {
@@ -1570,6 +1735,8 @@ __device__ __forceinline__ RoundSrc<Ops> round_src(const unsigned *__restrict__ 
     R.stride = lane < 16 ? (size_t)16 : (size_t)(Ops::WORDS * P.w_stride);
     // (grouped launches read the caller's feature rows in place whatever C is: no column beyond the row)
     R.stager = lane < 16 + Ops::WW && (!Ops::GROUPED || lane < 16 || L.cbase + lane - 16 < P.C);
+    R.src2 = w + (Ops::WORDS * L.cbase + lane + 48);
+    R.stride2 = (size_t)(Ops::WORDS * P.w_stride);
     return R;
 }
 
@@ -1584,17 +1751,21 @@ __device__ __forceinline__ void stage_round(const uint2 *__restrict__ line, cons
         const int e = e0 + wave + u * NW;
         ai[u] = (e >= 1 && e <= n_line) ? (int)(e < SLOTS ? line[e].x : ext[e - SLOTS].x) : 0;
     }
-    unsigned v[8];
+    constexpr int TAIL = round_tail<Ops>();
+    unsigned v[8], v2[TAIL ? 8 : 1];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int e = e0 + wave + u * NW;
         v[u] = 0u;
+        if (TAIL) v2[u] = 0u;
         if (e >= 1 && e <= n_line && R.stager) v[u] = R.src[(size_t)(a0 + ai[u]) * R.stride];
+        if (TAIL && e >= 1 && e <= n_line && lane < TAIL) v2[u] = R.src2[(size_t)(a0 + ai[u]) * R.stride2];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int sl = wave + u * NW, e = e0 + sl;
         if (e >= 1 && e <= n_line && (R.stager || (Ops::GROUPED && lane < 16 + Ops::WW))) un[sl * SW + lane] = v[u]; // (v = 0 beyond C)
+        if (TAIL && e >= 1 && e <= n_line && lane < TAIL) un[sl * SW + 64 + lane] = v2[u];
     }
 }
 
@@ -1678,12 +1849,12 @@ struct SlabOps<32, GAUSS, false, true, true> {
 };
 #endif
 
-template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT, bool GROUPED = false>
-__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
-    voxelize_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
-                    const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
-                    const VoxParams P) {
-    typedef typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE, GROUPED>::type Ops;
+// One workgroup = one slab: the body shared by voxelize_kernel (float32 grids, 64 registers, four 8-wave workgroups per
+// compute unit) and voxelize64_kernel (float64 grids on the matrix cores, 128 registers, two).
+template <typename Ops, int CT, bool CHANWISE, bool GROUPED>
+__device__ __forceinline__ void voxelize_slab(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
+                                              const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc,
+                                              void *__restrict__ out, const VoxParams &P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1805,6 +1976,22 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
 #ifdef MVX_DIAG
     if (g_diag && tid == 0) g_diag[16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 7] = n_hdr;
 #endif
+}
+
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT, bool GROUPED = false>
+__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
+    voxelize_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
+                    const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
+                    const VoxParams P) {
+    voxelize_slab<typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE, GROUPED>::type, CT, CHANWISE, GROUPED>(rec, w, slist, slist_ext, Tc, kc, out, P);
+}
+
+// float64 grids, chunks of 32 channels, scalar / atom-wise radii: the slab body with OpsMx64 (128 registers)
+template <bool GAUSS, bool LANE_RANGE, int MAXT>
+__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 4 : 2))
+    voxelize64_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
+                      const uint2 *__restrict__ slist_ext, double *__restrict__ out, const VoxParams P) {
+    voxelize_slab<OpsMx64<GAUSS, LANE_RANGE>, 32, false, false>(rec, w, slist, slist_ext, nullptr, nullptr, out, P);
 }
 
 // The general slab loop. float32: over the overflow list of the voxelize_kernel launches. float64: `overflow` is
@@ -2587,7 +2774,32 @@ hipError_t launch_voxelize_grouped(const VoxArgs &a, int32_t nb, bool gauss, boo
     return for_kernel(k, GroupedFn{a, nb, s});
 }
 
+template <bool GAUSS, bool LANE_RANGE>
+static hipError_t launch_mx64(const VoxArgs &a, hipStream_t s) {
+    static LdsLimit raised;
+    VoxParams p = a.p;
+    const size_t lds = voxelize_mx64_lds_bytes(p.NW);
+    auto kern = &voxelize64_kernel<GAUSS, LANE_RANGE, 512>;
+    hipError_t e = raise_lds_limit(kern, lds, raised);
+    if (e != hipSuccess) return e;
+    const int per = 65535 / p.ncc; // molecules per launch (gridDim.y limit); the profiling bracket rides on the first launch
+    for (int m0 = 0; m0 < p.B; m0 += per) {
+        p.b0 = m0;
+        const int nb = p.B - m0 < per ? p.B - m0 : per;
+        launch_profiled(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), lds, s, a.rec, a.w, a.slist,
+                        a.slist_ext, static_cast<double *>(a.out), p);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s) {
+    // chunks of 32 channels with scalar / atom-wise radii on 8-wave slabs: the matrix-core slab kernel
+    if (ct == 32 && !chanwise && a.p.NW <= 8 && a.p.dcap == 0) {
+        if (gauss) return lane_range ? launch_mx64<true, true>(a, s) : launch_mx64<true, false>(a, s);
+        return lane_range ? launch_mx64<false, true>(a, s) : launch_mx64<false, false>(a, s);
+    }
     KernelKey k{ct, gauss, chanwise, chanwise ? true : lane_range, 512};
     return for_kernel(k, Dense64Fn{a, s});
 }
