@@ -128,7 +128,10 @@ def make_cfg4_shard(total: int, rank: int, world: int):
     return wl, lo, hi
 
 
-PREWARM_LAUNCHES = 30  # fixed, disclosed in the JSON line: the clock ramp after an idle period lasts ~15 launches
+# Fixed pre-warm, disclosed in the JSON line (`prewarm_launches`). On a box that has been idle the kernel settles in two
+# stages: the first ~15 launches run up to 18 % slower, and the next ~100 still 2-3 % slower (cold box, 30 + 5 warm-up
+# launches: kernel 1.425-1.445 ms; the same command a minute later: 1.390-1.417 ms). 200 launches = 0.3 s per rank.
+PREWARM_LAUNCHES = 200
 
 
 def _free_port() -> int:

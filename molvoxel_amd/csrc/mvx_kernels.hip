@@ -1532,24 +1532,18 @@ struct OpsMx64 {
                              (iy <= (int)(rg.w >> 16));
                 }
             }
-            double val[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) val[m] = hit[m] ? 1.0 : 0.0;
-            if (GAUSS) {
-                const double c64 = *reinterpret_cast<const double *>(r + 14);
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    if (__ballot(hit[m]) != 0ull) { // (wave-uniform: exp is ~45 float64 instructions)
-                        const double e = exp(c64 * d2[m]);
-                        val[m] = hit[m] ? e : 0.0;
-                    }
-            }
             const double w0 = valid ? *reinterpret_cast<const double *>(r + 16 + 2 * j) : 0.0;        // channel j of the row
             const double w1 = valid ? *reinterpret_cast<const double *>(r + 16 + 2 * (16 + j)) : 0.0; // channel 16 + j
+            const double c64 = GAUSS ? *reinterpret_cast<const double *>(r + 14) : 0.0;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                acc.a[0][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, val[m], acc.a[0][m], 0, 0, 0);
-                acc.a[1][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, val[m], acc.a[1][m], 0, 0, 0);
+            for (int m = 0; m < 4; ++m) { // (one voxel block at a time: its value lives only until its two MFMAs are issued)
+                double val = hit[m] ? 1.0 : 0.0;
+                if (GAUSS && __ballot(hit[m]) != 0ull) { // (wave-uniform: exp is ~45 float64 instructions)
+                    const double e = exp(c64 * d2[m]);
+                    val = hit[m] ? e : 0.0;
+                }
+                acc.a[0][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, val, acc.a[0][m], 0, 0, 0);
+                acc.a[1][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, val, acc.a[1][m], 0, 0, 0);
             }
         }
     }
@@ -1863,7 +1857,37 @@ __device__ __forceinline__ void voxelize_slab(const unsigned *__restrict__ rec, 
     unsigned *un = reinterpret_cast<unsigned *>(smem);
 
     // grid = (T, Z): t = slab id, z = (molecule - b0) * ncc + channel chunk
-    const unsigned t = blockIdx.x;
+    unsigned t = blockIdx.x;
+#ifdef MVX_ZC_PAIR // (A/B builds) grids whose rows are cut into two slabs (D = 128): the two halves of a row on blocks k and k + 8
+    if (P.nzc == 2 && (gridDim.x & 15u) == 0) t = (t & ~15u) | ((t & 7u) << 1) | ((t >> 3) & 1u);
+#endif
+#ifndef MVX_ORDER
+#define MVX_ORDER 1
+#endif
+#ifndef MVX_ORDER_ROWS // (A/B builds) 1: apply MVX_ORDER to grids of one slab per row too
+#define MVX_ORDER_ROWS 0
+#endif
+    // Which slabs run side by side (blocks are dealt round-robin over the 8 XCDs, ~1000 resident at a time). Grids with
+    // several slabs per row (D > 64: a slab is half a 512-B row at D = 128): consecutive blocks take consecutive x-slabs -
+    // the resident workgroups then write pieces of every (channel, x) plane instead of filling 32 x planes densely: cfg-5
+    // x 8 0.676 -> 0.693 of peak, one cfg-5 call 61.8 -> 61.3 us (same box, twice). Measured and rejected there: the two
+    // halves of a row on blocks k and k + 8 (same XCD) 0.58; y fastest 0.56; 8 / 16 x-slabs side by side, then z, y:
+    // 0.694 / 0.668. Grids of one slab per row (D <= 64) keep z, y, x order: x-slabs fastest costs cfg-2 8 % (0.70).
+    if (P.nzc > 1 || MVX_ORDER_ROWS) {
+        const unsigned per_x = (unsigned)(P.nsy * P.nzc), nsx = (unsigned)P.nsx;
+        if (MVX_ORDER == 1) { // consecutive blocks = consecutive x-slabs
+            t = (t % nsx) * per_x + t / nsx;
+        } else if (MVX_ORDER == 2) { // eight x-slabs side by side (one per XCD), then z, y, the rest of x
+            const unsigned lo = t & 7u, rest = t >> 3, inner = rest % per_x, hi = rest / per_x;
+            t = (hi * 8u + lo) * per_x + inner;
+        } else if (MVX_ORDER == 3) { // y fastest, then z, then x
+            const unsigned sxx = t / per_x, r2 = t % per_x, syy = r2 % (unsigned)P.nsy, zz = r2 / (unsigned)P.nsy;
+            t = zz + (unsigned)P.nzc * (syy + (unsigned)P.nsy * sxx);
+        } else if (MVX_ORDER == 4) { // sixteen x-slabs side by side
+            const unsigned lo = t & 15u, rest = t >> 4, inner = rest % per_x, hi = rest / per_x;
+            t = (hi * 16u + lo) * per_x + inner;
+        }
+    }
     int b = (int)blockIdx.y, cc = 0;
     if (P.ncc > 1) {
         b = (int)blockIdx.y / P.ncc;
