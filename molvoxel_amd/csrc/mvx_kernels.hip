@@ -1409,9 +1409,9 @@ struct OpsMx32 {
         // this lane's voxel column in the tile, and the first of its four channels of a round
         const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1), h = lane >> 5;
         float *mine = tile + (4 * h * RPC + ly) * RS + SUBZ * wave + lz; // + (c * RPC + x * SUBY) * RS
-#pragma unroll
-        for (int rd = 0; rd < NROUND; ++rd) {
-            __syncthreads(); // candidate rows (round 0) / previous tile (later rounds) fully consumed
+        auto round = [&](auto rd_) {
+            constexpr int rd = decltype(rd_)::value;
+            __syncthreads(); // candidate rows (first round) / previous tile (later rounds) fully consumed
             if (rd == 0) VK_STAMP(4); // every wave's walk is done
             if (rd == 1) VK_STAMP(5); // round 0 transposed and its stores issued
 #pragma unroll
@@ -1437,7 +1437,26 @@ struct OpsMx32 {
                     }
                 }
             }
+        };
+        typedef std::integral_constant<int, 0> R0;
+        typedef std::integral_constant<int, 1> R1;
+        typedef std::integral_constant<int, 2> R2;
+        typedef std::integral_constant<int, 3> R3;
+        static_assert(NROUND == 4, "the rotation below spells out four rounds");
+#ifdef MVX_ROT // (A/B builds) workgroups start their channel rounds at different channel groups - measured, no gain: by
+               // blockIdx.x / 8: cfg-2 0.743 against 0.768, cfg-5 x 8 0.683 against 0.699; by blockIdx.x + y: 0.768 / 0.703
+        switch ((MVX_ROT == 1 ? (blockIdx.x >> 3) : (blockIdx.x + blockIdx.y)) & 3u) {
+        case 1: round(R1{}); round(R2{}); round(R3{}); round(R0{}); break;
+        case 2: round(R2{}); round(R3{}); round(R0{}); round(R1{}); break;
+        case 3: round(R3{}); round(R0{}); round(R1{}); round(R2{}); break;
+        default: round(R0{}); round(R1{}); round(R2{}); round(R3{}); break;
         }
+#else
+        round(R0{});
+        round(R1{});
+        round(R2{});
+        round(R3{});
+#endif
     }
 };
 
