@@ -1862,171 +1862,13 @@ struct SlabOps<32, GAUSS, false, true, true> {
 };
 #endif
 
-// One workgroup = one slab: the body shared by voxelize_kernel (float32 grids, 64 registers, four 8-wave workgroups per
-// compute unit) and voxelize64_kernel (float64 grids on the matrix cores, 128 registers, two).
-template <typename Ops, int CT, bool CHANWISE, bool GROUPED>
-__device__ __forceinline__ void voxelize_slab(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
-                                              const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc,
-                                              void *__restrict__ out, const VoxParams &P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = P.NW;
-    unsigned *un = reinterpret_cast<unsigned *>(smem);
-
-    // grid = (T, Z): t = slab id, z = (molecule - b0) * ncc + channel chunk
-    unsigned t = blockIdx.x;
-#ifdef MVX_ZC_PAIR // (A/B builds) grids whose rows are cut into two slabs (D = 128): the two halves of a row on blocks k and k + 8
-    if (P.nzc == 2 && (gridDim.x & 15u) == 0) t = (t & ~15u) | ((t & 7u) << 1) | ((t >> 3) & 1u);
-#endif
-#ifndef MVX_ORDER
-#define MVX_ORDER 1
-#endif
-#ifndef MVX_ORDER_ROWS // (A/B builds) 1: apply MVX_ORDER to grids of one slab per row too
-#define MVX_ORDER_ROWS 0
-#endif
-    // Which slabs run side by side (blocks are dealt round-robin over the 8 XCDs, ~1000 resident at a time). Grids with
-    // several slabs per row (D > 64: a slab is half a 512-B row at D = 128): consecutive blocks take consecutive x-slabs -
-    // the resident workgroups then write pieces of every (channel, x) plane instead of filling 32 x planes densely: cfg-5
-    // x 8 0.676 -> 0.693 of peak, one cfg-5 call 61.8 -> 61.3 us (same box, twice). Measured and rejected there: the two
-    // halves of a row on blocks k and k + 8 (same XCD) 0.58; y fastest 0.56; 8 / 16 x-slabs side by side, then z, y:
-    // 0.694 / 0.668. Grids of one slab per row (D <= 64) keep z, y, x order: x-slabs fastest costs cfg-2 8 % (0.70).
-    if (P.nzc > 1 || MVX_ORDER_ROWS) {
-        const unsigned per_x = (unsigned)(P.nsy * P.nzc), nsx = (unsigned)P.nsx;
-        if (MVX_ORDER == 1) { // consecutive blocks = consecutive x-slabs
-            t = (t % nsx) * per_x + t / nsx;
-        } else if (MVX_ORDER == 2) { // eight x-slabs side by side (one per XCD), then z, y, the rest of x
-            const unsigned lo = t & 7u, rest = t >> 3, inner = rest % per_x, hi = rest / per_x;
-            t = (hi * 8u + lo) * per_x + inner;
-        } else if (MVX_ORDER == 3) { // y fastest, then z, then x
-            const unsigned sxx = t / per_x, r2 = t % per_x, syy = r2 % (unsigned)P.nsy, zz = r2 / (unsigned)P.nsy;
-            t = zz + (unsigned)P.nzc * (syy + (unsigned)P.nsy * sxx);
-        } else if (MVX_ORDER == 4) { // sixteen x-slabs side by side
-            const unsigned lo = t & 15u, rest = t >> 4, inner = rest % per_x, hi = rest / per_x;
-            t = (hi * 16u + lo) * per_x + inner;
-        }
-    }
-    int b = (int)blockIdx.y, cc = 0;
-    if (P.ncc > 1) {
-        b = (int)blockIdx.y / P.ncc;
-        cc = (int)blockIdx.y - b * P.ncc;
-    }
-    b += P.b0;
-    if constexpr (CHANWISE) { // the general per-channel kernel serves only what the grouped launch could not (ChanGroups)
-        const ChanGroups *G = reinterpret_cast<const ChanGroups *>(reinterpret_cast<const char *>(Tc) - sizeof(ChanGroups));
-        if (!G->fallback) return;
-    }
-    const ChanGroups *__restrict__ G = reinterpret_cast<const ChanGroups *>(Tc); // (grouped launches only)
-    if constexpr (GROUPED) {
-        if (G->fallback) return;
-    }
-    // the slab's candidate line: {count, first atom}, then {atom index, packed ranges} per candidate
-    const uint2 *__restrict__ line = slist + ((size_t)b * (size_t)gridDim.x + t) * SLOTS; // (uniform: scalar loads)
-    const uint2 hdr = line[0];
-    int sx, sy, zc;
-    decode_slab(t, P, sx, sy, zc);
-    const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NW;
-    LaneCtx L = Ops::ctx(lane, wave, x0, y0, z0, zc * NW, P.c0 + cc * CT, P);
-    if constexpr (GROUPED) {
-        // the radius slot of this lane's channel, the slots present in the chunk, {T, k} of every slot in LDS
-        const int *chan_slot = reinterpret_cast<const int *>(kc);
-        const int ch = L.cbase + (lane & 31);
-        L.grp = ch < P.C ? chan_slot[ch] : -1;
-        unsigned present = 0;
-#pragma unroll
-        for (int g = 0; g < CHAN_GROUP_SLOTS; ++g) present |= (__ballot(L.grp == g) != 0ull) ? (1u << g) : 0u; // (uniform)
-        L.gmask = present;
-        double *gtab = reinterpret_cast<double *>(smem + P.dcap); // (P.dcap: bytes of the rows / tile region in grouped launches)
-        if (tid < 2 * CHAN_GROUP_SLOTS) gtab[tid] = reinterpret_cast<const double *>(&G->slot[0])[tid];
-        L.gtab = gtab;
-        // (published by the staging barrier, which every walk sits behind)
-    }
-
-    typename Ops::Acc acc;
-    Ops::zero(acc);
-
-    VK_STAMP(0);
-    const unsigned n_hdr = __builtin_amdgcn_readfirstlane(hdr.x);
-    const int64_t a0 = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane(hdr.y);
-    VK_STAMP(1); // the line has arrived
-    const int RW = 8 * NW < 64 ? 8 * NW : 64; // rows staged per round
-    if (n_hdr > 0) {
-        // The normal case is one round over the slab's line (<= 63 candidates, cfg-2: ~45). More candidates than one round
-        // of rows (dense slabs: larger radii) take further rounds over the line and its extension, the accumulators carried
-        // along. (Round 1 sent such slabs to a second kernel with two workgroups per compute unit: with a 1.5 A radius on
-        // cfg-2 that launch took 230 of the step's 618 us.)
-        // LINE_OVERFLOW - more candidates than line + extension hold (dense clusters; never at protein densities): the
-        // slab's "line" then is the (molecule, x-slab) list itself, any length, in atom order (entry e >= 1 at
-        // list[XL_HEADER - 1 + e]): every listed atom's row is staged, and the row filter drops the ones that miss the
-        // slab's y rows. (Until round 3 such slabs were queued for that second kernel, whose launch cost 4.7 us per call
-        // whether or not the queue was empty.)
-        const bool xl = __builtin_expect(n_hdr > (unsigned)LINE_CAP, 0);
-        const uint2 *__restrict__ ext = slist_ext + ((size_t)b * (size_t)gridDim.x + t) * EXT_SLOTS;
-        int n = (int)n_hdr;
-        if (xl) {
-            // (xbin_kernel left the list's address in entry 1, for overflowing slabs only. An address rebuilt from loaded
-            // words is, to the compiler, a per-lane pointer into any address space: left at that, EVERY line entry of
-            // the hot path below is fetched with flat_load through the vector memory pipeline - behind the stores - instead
-            // of s_load: cfg-2 x 256 ran at 0.635 of peak against 0.79. Hence the explicit scalar halves and the global
-            // address space.)
-            const uint2 where = line[1];
-            const unsigned long long at = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)where.y) << 32) |
-                                          (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)where.x);
-            typedef const uint2 __attribute__((address_space(1))) *global_u2;
-            const global_u2 xlp = (global_u2)at;
-            n = __builtin_amdgcn_readfirstlane((int)xlp[0].x);
-            line = (const uint2 *)(xlp + (XL_HEADER - 1));
-            ext = line + SLOTS;
-        }
-        // (the first round is peeled: it is staged before the accumulators exist - with 32 accumulators live across the
-        // staging loads the kernel needs 90 VGPRs instead of 62 - and the normal case is this one round)
-        const RoundSrc<Ops> RS_ = round_src<Ops>(rec, w, lane, L, P);
-        stage_round<Ops>(line, ext, 0, n, un, RS_, a0, lane, wave, NW);
-        VK_STAMP(2);
-        __syncthreads();
-        VK_STAMP(3);
-#ifndef MVX_PREFETCH
-        // every further round is staged through registers after the walk before it. (-DMVX_PREFETCH, measured and not
-        // used: the next round's rows by LDS-DMA into a second row buffer while this round is walked - correct, and
-        // slower at every radius: 0.75 / 0.62 / 0.48 of peak at 1.0 / 1.5 / 2.0 A against 0.78 / 0.64 / 0.49; what a
-        // compute unit's four workgroups queue on is the vector memory pipeline as a whole, and 27 KB of LDS instead of
-        // 18 KB per workgroup costs more than the hidden latency buys.)
-        filter_walk<Ops>(xl, acc, 0, n, RW, un, lane, wave, L, P, Tc, kc);
-        for (int e0 = RW; e0 <= n; e0 += RW) {
-            __syncthreads(); // every wave is done with the previous round's rows
-            stage_round<Ops>(line, ext, e0, n, un, RS_, a0, lane, wave, NW);
-            __syncthreads();
-            filter_walk<Ops>(xl, acc, e0, n, RW, un, lane, wave, L, P, Tc, kc);
-        }
-#else
-        // two row buffers: round r is walked from buffer r % 2 while the rows of round r + 1 arrive in the other one
-        unsigned *buf = un, *other = un + 64 * Ops::SW;
-        for (int e0 = 0;; e0 += RW) {
-            const bool more = e0 + RW <= n; // (uniform)
-            if (more) prefetch_round<Ops>(line, ext, e0 + RW, n, other, RS_, a0, wave, NW);
-            filter_walk<Ops>(xl, acc, e0, n, RW, buf, lane, wave, L, P, Tc, kc);
-            if (!more) break;
-            __syncthreads(); // this wave's DMA has landed (vmcnt(0)); everyone's has, and everyone is done with `buf`
-            unsigned *t = buf;
-            buf = other;
-            other = t;
-        }
-#endif
-    }
-    Ops::write(acc, n_hdr > 0, un, tid, lane, wave, NW, b, L, x0, y0, z0, out, P);
-    VK_STAMP(6); // all stores issued
-#ifdef MVX_DIAG
-    if (g_diag && tid == 0) g_diag[16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 7] = n_hdr;
-#endif
-}
-
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT, bool GROUPED = false>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
     voxelize_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
                     const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
                     const VoxParams P) {
-    voxelize_slab<typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE, GROUPED>::type, CT, CHANWISE, GROUPED>(rec, w, slist, slist_ext, Tc, kc, out, P);
+    typedef typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE, GROUPED>::type Ops;
+#include "mvx_slab_body.inc"
 }
 
 // float64 grids, chunks of 32 channels, scalar / atom-wise radii: the slab body with OpsMx64 (128 registers)
@@ -2034,7 +1876,12 @@ template <bool GAUSS, bool LANE_RANGE, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 4 : 2))
     voxelize64_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
                       const uint2 *__restrict__ slist_ext, double *__restrict__ out, const VoxParams P) {
-    voxelize_slab<OpsMx64<GAUSS, LANE_RANGE>, 32, false, false>(rec, w, slist, slist_ext, nullptr, nullptr, out, P);
+    typedef OpsMx64<GAUSS, LANE_RANGE> Ops;
+    constexpr int CT = 32;
+    constexpr bool CHANWISE = false, GROUPED = false;
+    const double *const Tc = nullptr;
+    const float *const kc = nullptr;
+#include "mvx_slab_body.inc"
 }
 
 // The general slab loop. float32: over the overflow list of the voxelize_kernel launches. float64: `overflow` is

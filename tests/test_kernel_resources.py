@@ -1,0 +1,57 @@
+"""Register budgets of the hot kernels, read from the built code object (no GPU needed).
+
+The voxelize kernels live at an occupancy edge - 64 VGPRs for four 8-wave workgroups per compute unit - and a structural
+edit elsewhere in the translation unit has twice pushed one variant's accumulators into scratch without any test noticing
+(round 3: 193 spilled registers in the per-lane-range 32-channel variant after the slab body became an inlined function).
+These bounds are what the shipped build measures plus a little slack; a change that breaks them should be looked at in
+the disassembly (tools/disasm.sh) before it is accepted.
+"""
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJ = os.path.join(ROOT, "molvoxel_amd", "csrc", "mvx_kernels.o")
+
+
+@pytest.fixture(scope="module")
+def res():
+    if not os.path.exists(OBJ):
+        pytest.skip("mvx_kernels.o not built (python -c 'import __graft_entry__ as g; g.build()')")
+    from tools import regs
+
+    return regs.kernel_resources(OBJ)
+
+
+def test_batched_voxelize_kernels_fit_their_occupancy(res):
+    ks = {k: v for k, v in res.items() if k.startswith("voxelize_kernel<") and ", 512, " in k}
+    assert len(ks) >= 30
+    for name, r in ks.items():
+        assert r["vgpr"] <= 64, (name, r)  # 8 waves per SIMD
+    # the headline kernel (32 channels, gaussian, matrix-core walk) and its binary twin: no scratch in the first round
+    for name in ("voxelize_kernel<32, true, false, false, 512, false>", "voxelize_kernel<32, false, false, false, 512, false>"):
+        assert res[name]["scratch"] <= 32 and res[name]["vspill"] <= 6, (name, res[name])
+    # narrower chunks (ligand batches, forward_types, forward_single): none at all
+    for ct in (1, 4, 8, 16):
+        for gauss in ("true", "false"):
+            r = res[f"voxelize_kernel<{ct}, {gauss}, false, false, 512, false>"]
+            assert r["scratch"] == 0 and r["vspill"] == 0, (ct, gauss, r)
+    # per-lane-range variants (blockdim 4, 5, 12, ...): a handful of spills in the cold rounds, never the accumulators
+    for name, r in ks.items():
+        if name.startswith("voxelize_kernel<32,") and ", false, true, 512, false>" in name:
+            assert r["vspill"] <= 16 and r["scratch"] <= 80, (name, r)
+
+
+def test_float64_matrix_core_kernel_keeps_two_workgroups_per_unit(res):
+    for name, r in res.items():
+        if name.startswith("voxelize64_kernel<"):
+            assert r["vgpr"] <= 128, (name, r)
+            assert r["scratch"] <= 160, (name, r)
+    assert res["voxelize64_kernel<false, false, 512>"]["scratch"] == 0
+
+
+def test_prepass_kernels_do_not_spill_vector_registers(res):
+    assert res["prep_kernel"]["vspill"] == 0 and res["prep_kernel"]["scratch"] == 0
+    for name, r in res.items():
+        if name.startswith("xbin_kernel<"):
+            assert r["vspill"] == 0 and r["scratch"] == 0, (name, r)

@@ -1,4 +1,4 @@
-"""Register / LDS / scratch use of every kernel in a built library, read from the gfx950 code object's metadata notes.
+"""Register / LDS / scratch use of every kernel in a built object or library, read from the gfx950 code object's metadata.
 
     python3 tools/regs.py [path/to/lib.so or .o] [substring ...]      default: molvoxel_amd/csrc/mvx_kernels.o
 """
@@ -6,29 +6,35 @@ import os, re, subprocess, sys, tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-obj = sys.argv[1] if len(sys.argv) > 1 and os.path.exists(sys.argv[1]) else os.path.join(ROOT, "molvoxel_amd/csrc/mvx_kernels.o")
-pats = [a for a in sys.argv[1:] if not os.path.exists(a)]
-with tempfile.TemporaryDirectory() as td:
-    co = os.path.join(td, "k.co")
-    fat = os.path.join(td, "fat.bin")
-    subprocess.check_call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj, os.path.join(td, "ignored")])
-    subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", f"--output={co}",
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], stderr=subprocess.DEVNULL)
-    notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
-rows = []
-for blk in re.split(r"\n\s*- \.agpr_count:", notes)[1:]:
-    def g(key):
-        m = re.search(rf"\.{key}:\s*(\S+)", blk)
-        return m.group(1) if m else "?"
-    name = g("name")
-    try:
-        name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
-    except Exception:
-        pass
-    rows.append((name, g("vgpr_count"), g("sgpr_count"), g("vgpr_spill_count"), g("sgpr_spill_count"), g("private_segment_fixed_size"),
-                 g("group_segment_fixed_size")))
-for r in sorted(rows):
-    short = re.sub(r"\(.*", "", r[0]).replace("void mvx::", "")
-    if pats and not any(p in short for p in pats):
-        continue
-    print(f"{short:75s} vgpr {r[1]:>4s} sgpr {r[2]:>4s} vspill {r[3]:>3s} sspill {r[4]:>3s} scratch {r[5]:>4s} lds {r[6]:>6s}")
+DEFAULT_OBJ = os.path.join(ROOT, "molvoxel_amd/csrc/mvx_kernels.o")
+
+
+def kernel_resources(obj=DEFAULT_OBJ):
+    """{demangled kernel name (without 'void mvx::' and the argument list): dict(vgpr, sgpr, vspill, sspill, scratch, lds)}"""
+    with tempfile.TemporaryDirectory() as td:
+        co, fat = os.path.join(td, "k.co"), os.path.join(td, "fat.bin")
+        subprocess.check_call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj, os.path.join(td, "ignored")])
+        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", f"--output={co}",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], stderr=subprocess.DEVNULL)
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+    blocks = re.split(r"\n\s*- \.agpr_count:", notes)[1:]
+    names = [re.search(r"\.name:\s*(\S+)", b).group(1) for b in blocks]
+    demangled = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    out = {}
+    for blk, name in zip(blocks, demangled):
+        def g(key):
+            m = re.search(rf"\.{key}:\s*(\d+)", blk)
+            return int(m.group(1)) if m else -1
+        short = re.sub(r"\(.*", "", name).replace("void mvx::", "").replace("mvx::", "")
+        out[short] = dict(vgpr=g("vgpr_count"), sgpr=g("sgpr_count"), vspill=g("vgpr_spill_count"), sspill=g("sgpr_spill_count"),
+                          scratch=g("private_segment_fixed_size"), lds=g("group_segment_fixed_size"))
+    return out
+
+
+if __name__ == "__main__":
+    obj = sys.argv[1] if len(sys.argv) > 1 and os.path.exists(sys.argv[1]) else DEFAULT_OBJ
+    pats = [a for a in sys.argv[1:] if not os.path.exists(a)]
+    for short, r in sorted(kernel_resources(obj).items()):
+        if pats and not any(p in short for p in pats):
+            continue
+        print(f"{short:75s} vgpr {r['vgpr']:4d} sgpr {r['sgpr']:4d} vspill {r['vspill']:3d} sspill {r['sspill']:3d} scratch {r['scratch']:4d} lds {r['lds']:6d}")
