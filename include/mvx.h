@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MVX_VERSION 120 /* 0.1.2: mvx_xform.center_ptr, stream hand-over, unaligned out, mvx_debug_set_option */
+#define MVX_VERSION 130 /* 0.1.3: one voxelize launch per batched call (no second kernel), channel-wise radii grouped on the device; the ABI itself is unchanged since 0.1.2 (mvx_xform.center_ptr, stream hand-over, unaligned out, mvx_debug_set_option) */
 
 typedef enum mvx_status {
     MVX_OK = 0,
