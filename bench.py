@@ -176,7 +176,9 @@ class Ranks:
     def __init__(self, world: int, rank: int, device, own_gpu: bool):
         self.world, self.rank, self.device = world, rank, device
         self.dist, self.nccl, self.backend, self.note = None, None, None, None
-        if world == 1:
+        # (MVX_BENCH_COLLECTIVES=1 under a one-rank launcher: set the groups up all the same - the way the suite exercises
+        # the RCCL branch on a box with a single GPU)
+        if world == 1 and os.environ.get("MVX_BENCH_COLLECTIVES") != "1":
             return
         import datetime
 

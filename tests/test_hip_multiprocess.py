@@ -100,3 +100,20 @@ def test_bare_bench_py_starts_its_own_ranks_on_the_hip_path(n, extra):
     assert rec["n_gpus"] == n and rec["ranks_seen"] == n and rec["parity_spot"] == "ok" and rec["scaling"] == "weak"
     assert rec["collective_backend"] in ("gloo", "nccl") and rec["value"] > 0 and rec["prewarm_launches"] >= 1
     assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1.2
+
+
+def test_bench_py_rccl_branch_with_one_rank():
+    """The barrier / MAX over RCCL - what an 8-GPU run uses when every rank has its own GPU - cannot be reached with two
+    ranks on one card (RCCL refuses two ranks per device). One rank under the launcher with the collectives forced on
+    runs exactly that code: gloo group, RCCL sub-group, probe all-reduce, agreement, barrier, MAX, gather."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MVX_BENCH_COLLECTIVES"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch", "8", "--cpu-seconds", "0"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+    assert res.returncode == 0, res.stdout[-3000:]
+    rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["collective_backend"] == "nccl" and rec["ranks_seen"] == 1 and rec["parity_spot"] == "ok", rec.get("collective_note")
