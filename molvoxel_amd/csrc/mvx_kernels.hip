@@ -1470,6 +1470,42 @@ struct OpsMx32 {
 // eight MFMAs (4 voxel blocks x 2 channel blocks, A = 16 channel weights of the candidate, B = the block's values).
 // The vector path spent 32 float64 FMAs (128 issue cycles) and sixteen 16-byte LDS reads per candidate and wave on this.
 typedef double d4v __attribute__((ext_vector_type(4)));
+// exp(x) for x <= 0 in float64, for the matrix-core float64 walk: the library's exp is ~45 float64 instructions and, four
+// per lane and candidate group, was what that walk spent most of its vector issue (and 27 spilled registers) on.
+// x = (64 m + j) ln2 / 64 + r, |r| <= ln2 / 128: exp(x) = 2^m * 2^(j/64) * (1 + expm1(r)), the 64 table values correctly
+// rounded (generated with 60-digit decimals), ln2 / 64 split so that k * LN2_64_HI is exact for |k| < 2^20, expm1 by its
+// series to r^6 (the next term is below 3e-20 relative): ~1 ulp, like the library's (the reference's own chain of sqrt, two
+// divisions and a square puts its argument ~4 ulp away already; the float64 goldens hold values to 1e-12).
+__constant__ double EXP2_64TH[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+__device__ __forceinline__ double exp_nonpos64(double x, const double *__restrict__ tab /* LDS copy of EXP2_64TH */) {
+    const double kd = __builtin_rint(x * 0x1.71547652b82fep+6); // 64 / ln2
+    double r = fma(-kd, 0x1.62e42fee00000p-7, x);                // ln2 / 64, upper 32 bits
+    r = fma(-kd, 0x1.a39ef35793c76p-39, r);                       // ... and the rest
+    const int ki = (int)kd;
+    const double t = tab[ki & 63];
+    double q = fma(0x1.6c16c16c16c17p-10, r, 0x1.1111111111111p-7); // 1/720, 1/120
+    q = fma(q, r, 0x1.5555555555555p-5);                             // 1/24
+    q = fma(q, r, 0x1.5555555555555p-3);                             // 1/6
+    q = fma(q, r, 0.5);
+    const double p = fma(q * r, r, r); // expm1(r)
+    return ldexp(fma(t, p, t), ki >> 6);
+}
 constexpr int MX64_SW = 84; // 16 + 64 words, padded to an odd number of 16-B quads (one row per lane in the row filter)
 size_t voxelize_mx64_lds_bytes(int32_t NW) {
     const size_t rows = (size_t)64 * MX64_SW * 4;
@@ -1557,8 +1593,8 @@ struct OpsMx64 {
 #pragma unroll
             for (int m = 0; m < 4; ++m) { // (one voxel block at a time: its value lives only until its two MFMAs are issued)
                 double val = hit[m] ? 1.0 : 0.0;
-                if (GAUSS && __ballot(hit[m]) != 0ull) { // (wave-uniform: exp is ~45 float64 instructions)
-                    const double e = exp(c64 * d2[m]);
+                if (GAUSS && __ballot(hit[m]) != 0ull) { // (wave-uniform)
+                    const double e = exp_nonpos64(c64 * d2[m], L.gtab);
                     val = hit[m] ? e : 0.0;
                 }
                 acc.a[0][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, val, acc.a[0][m], 0, 0, 0);
@@ -2668,7 +2704,8 @@ template <bool GAUSS, bool LANE_RANGE>
 static hipError_t launch_mx64(const VoxArgs &a, hipStream_t s) {
     static LdsLimit raised;
     VoxParams p = a.p;
-    const size_t lds = voxelize_mx64_lds_bytes(p.NW);
+    const size_t main_lds = voxelize_mx64_lds_bytes(p.NW), lds = main_lds + 512;
+    p.dcap = (int32_t)main_lds; // where the kernel keeps its copy of the 2^(j/64) table
     auto kern = &voxelize64_kernel<GAUSS, LANE_RANGE, 512>;
     hipError_t e = raise_lds_limit(kern, lds, raised);
     if (e != hipSuccess) return e;
