@@ -191,7 +191,7 @@ def test_c_abi_direct_host_pointers(mv):
     from oracle import c_oracle
 
     lib = _lib.load()
-    assert lib.mvx_version() == 120
+    assert lib.mvx_version() == 130  # MVX_VERSION of include/mvx.h
     wl = W.cfg3()
     cfg = _lib.MvxConfig(0.5, 0.5, 48, 8, _lib.MVX_BINARY, 0, 32, 0)
     h = _lib.Handle()
