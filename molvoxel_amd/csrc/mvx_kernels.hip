@@ -16,11 +16,14 @@
 //   voxelize_kernel  one workgroup per output slab of 2 x 4 x (8*NW) voxels (NW waves, one 2x4x8 sub-tile per
 //                    wave, one voxel per lane, CT channel accumulators per lane in registers): load the slab's
 //                    candidate line, stage the candidates' rows in LDS, every wave walks the candidates that
-//                    touch its sub-tile (fp64 d2, compare with T, exp2, packed FMAs), then the accumulators are
+//                    touch its sub-tile (fp64 d2, compare with T, exp2, channel update), then the accumulators are
 //                    transposed through LDS and written with non-temporal 16-B/lane stores in whole-row runs.
 //                    Every output byte is written exactly once, zeros included (the reference's overwrite
 //                    semantics, numpy/voxelizer.py:133-135,158-160); no atomics, no memset, no (V, DHW)
-//                    intermediate, no MFMA (scatter-reduce, HBM-write bound).
+//                    intermediate; HBM-write bound. The channel update of 32-channel chunks - the one dense
+//                    contraction in the walk, the reference's own matmul - runs on the matrix cores in exact
+//                    float32 (OpsMx32: v_mfma_f32_32x32x2_f32, bit-identical to the fmaf chain), narrower chunks on
+//                    the vector ALU (packed FMAs).
 //
 // Exactness: membership float32(float32(sqrt_f64(d2))/r32) <= 1 is equivalent to d2 <= T with
 //   y  = largest fp64 whose float32 rounding is <= r32,  T = round_down(y * nextup(y))
@@ -854,7 +857,7 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
 // ------------------------------------------------------------------------------------------------
 // Shared decomposition: one slab = SUBX x SUBY x (SUBZ*NW) voxels = NW waves, one 64-voxel sub-tile per wave, one
 // voxel per lane, CT channel accumulators per lane in registers. Every output byte is written exactly once (zeros
-// included) with 16-B/lane non-temporal stores in whole-row runs; no atomics, no memset, no MFMA.
+// included) with 16-B/lane non-temporal stores in whole-row runs; no atomics, no memset.
 //
 // voxelize_kernel (built for the normal case: the slab's primary line holds all its candidates, <= 63).
 //   grid = (slab id, molecule * ncc + channel chunk), one workgroup per slab:
@@ -862,18 +865,21 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
 //        through the scalar path;
 //     2. stage: wave w copies the rows of candidates w, w+NW, ... (64-B record + CT channel weights, one coalesced
 //        load each, all loads in flight at once) into LDS; one barrier;
-//     3. walk: each wave picks the candidates whose z range touches its sub-tile from the staged records (one lane per
-//        row + ballot) and processes them: broadcast LDS reads, fp64 d2 in cdist order, compare with T, exp2,
-//        software-pipelined weight reads + packed FMAs;
-//     4. write-out: accumulators -> LDS tile (CR = min(CT, MVX_CR = 4) channels per round) -> stores. Empty slabs skip the
-//        LDS round trip.
+//     3. walk: each wave picks the candidates that can reach its sub-tile from the staged records (one lane per row:
+//        z range, exact sphere / box cull; ballot) and processes them: fp64 d2 in cdist order, compare with T, exp2,
+//        then the channel update - vector ALU: broadcast LDS reads of the weight row, software-pipelined against packed
+//        FMAs; 32-channel chunks: two candidates per v_mfma_f32_32x32x2_f32 pair, two voxels per lane (OpsMx32);
+//     4. write-out: accumulators -> LDS tile (4 channels per round on the vector path, 8 on the matrix path) -> stores.
+//        Empty slabs skip the LDS round trip.
 //   A slab with 64..255 candidates repeats 1-3 over the rest of the line and its extension (rounds of 64 rows, the
-//   accumulators carried along); only a slab beyond that (LINE_OVERFLOW) appends its id to the overflow list and leaves.
-// voxelize_dense_kernel (the general slab loop; float32: over the overflow list, usually empty - then the launch returns
-//   at once, and it is not launched at all when no molecule has more than 255 atoms; float64 grids: over all slabs).
-//   Per slab: rounds of 64 entries over the primary + extension line (<= 255 candidates), or, beyond that, wave 0
-//   compacts the (molecule, x-slab) list in rounds of LCAP entries into an LDS list and the rows are staged in rounds
-//   of dcap; same walk and write-out.
+//   accumulators carried along); a slab beyond that (LINE_OVERFLOW) does the same over its (molecule, x-slab) list.
+//   Channel-wise radii for features: the GROUPED instantiation (one threshold / density per distinct radius and candidate);
+//   the CHANWISE instantiation (one per channel) only when there are more than 32 distinct radii.
+// voxelize64_kernel: the same slab body for float64 grids with chunks of 32 channels (OpsMx64, v_mfma_f64_16x16x4_f64).
+// voxelize_dense_kernel (the general slab loop, float64 grids of <= 16 channels or with channel-wise radii: grid-stride
+//   over all slabs). Per slab: rounds of 64 entries over the primary + extension line (<= 255 candidates), or, beyond
+//   that, wave 0 compacts the (molecule, x-slab) list in rounds of LCAP entries into an LDS list and the rows are staged
+//   in rounds of dcap; same walk and write-out.
 // LDS map (dynamic, 16-B aligned): voxelize_kernel: union { 64 x SW words of rows ; (CR*RPC rows) x RS floats tile };
 //   dense kernel: int list[LCAP] | uint32 zr[LCAP] | int nlist | union { dcap rows ; tile }, LCAP = 64 * min(NW, 4).
 
@@ -1920,8 +1926,8 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 4 : 2))
 #include "mvx_slab_body.inc"
 }
 
-// The general slab loop. float32: over the overflow list of the voxelize_kernel launches. float64: `overflow` is
-// null and the loop runs over all `total` (molecule, chunk, slab) ids.
+// The general slab loop (float64 grids that do not take voxelize64_kernel): all `total` (molecule, chunk, slab) ids,
+// grid-stride. (Until round 3 it also served the float32 overflow list.)
 template <typename Ops, int MAXT, int WPE>
 __global__ void __launch_bounds__(MAXT, WPE)
     voxelize_dense_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ xlist,

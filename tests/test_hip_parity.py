@@ -314,7 +314,7 @@ def test_dense_cluster_exceeds_candidate_capacity(mv):
     t = rng.integers(0, 3, 3000)
     v = mv.create_voxelizer(0.5, 24, "scalar", "binary", "hip", output="numpy")
     ref = c_oracle.voxelize(xyz, t, 1.0, dimension=24, density="binary", num_channels=3)
-    for route in (0, 1):  # binned: overflow list + dense kernel; direct: many rounds per slab
+    for route in (0, 1):  # binned: slabs beyond 255 candidates walk their x-list; direct: many rounds per slab
         v.debug_option("direct", route)
         assert np.array_equal(v.forward(xyz, None, t, 1.0), ref)
     f = rng.random((3000, 32)).astype(np.float32)
@@ -455,7 +455,7 @@ def test_ragged_batch_with_one_large_molecule(mv):
 def test_pipelined_chunks_match_single_stream(mv):
     """Batches of >= 8 molecules are cut into chunks whose pre-pass runs on a side stream (debug option "chunks"); results
     must not depend on the chunk count, and every chunk count must match the oracle (ragged sizes, empty
-    molecules, a dense cluster that takes the overflow list, random transforms)."""
+    molecules, a dense cluster whose slabs walk their x-lists, random transforms)."""
     from oracle import c_oracle
 
     rng = np.random.default_rng(21)
@@ -988,7 +988,7 @@ def test_per_molecule_fast_path_replayed_with_changing_arguments(mv):
 def test_batches_cut_for_the_infinity_cache_match_one_launch(mv):
     """Batches whose pre-pass data exceed the Infinity Cache budget run chunk by chunk (pre-pass, voxelize, pre-pass,
     voxelize ...; production budget 288 MB = 256 cfg-2 molecules). With the budget lowered, a ragged batch with a dense
-    cluster (overflow list shared by all chunks), empty molecules and per-molecule transforms must give the same bits as
+    cluster (slabs beyond line + extension in every chunk), empty molecules and per-molecule transforms must give the same bits as
     the single-launch run and match the oracle."""
     from oracle import c_oracle
 
