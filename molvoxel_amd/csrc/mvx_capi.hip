@@ -56,6 +56,10 @@ constexpr int NSLOTS = 4;
 // 30 / 44 us, 4 096 workgroups 31 / 63 us; 256 ligands in one call (131 072 workgroups) 0.64 / 2.04 ms ...
 constexpr double MALL_BUDGET = 288.0e6; // bytes of pre-pass data per voxelize launch (run(): chunking for the Infinity Cache)
 constexpr long long DIRECT_MAX_WORKGROUPS = 1536;
+#ifndef MVX_MX64_MIN_C
+#define MVX_MX64_MIN_C 16
+#endif
+constexpr int MX64_MIN_C = MVX_MX64_MIN_C; // float64 grids of more channels than this take the matrix-core slab kernel
 // ... and of at most this many atom tests (every workgroup scans its molecule's atoms: ~2 us per million)
 constexpr long long DIRECT_MAX_ATOM_TESTS = 16ll << 20;
 
@@ -399,10 +403,10 @@ int run(mvx_handle *h, const RunArgs &r) {
     // three 8-wave workgroups (26 dwords of scratch in the walk: 2.5 TB/s).
     // Round 3: more than 16 channels with scalar / atom-wise radii take chunks of 32 on 8-wave slabs through the
     // matrix-core slab kernel (voxelize64_kernel, 128 registers, two workgroups per unit): a.p.dcap == 0 selects it.
-    const bool mx64 = f64 && r.C > 16 && !(r.radii_type == MVX_RADII_CHANNEL && r.mode == MODE_FEATURES) && h->max_ct64 >= 32 &&
+    const bool mx64 = f64 && r.C > MX64_MIN_C && !(r.radii_type == MVX_RADII_CHANNEL && r.mode == MODE_FEATURES) && h->max_ct64 >= 32 &&
                       h->max_ct >= 32 && h->force_nw == 0;
     const SlabPlan sp = plan_slabs(h, 8);
-    const int ct = pick_ct(std::min(r.C, f64 ? (mx64 ? 32 : std::min(h->max_ct, 16)) : h->max_ct));
+    const int ct = mx64 ? 32 : pick_ct(std::min(r.C, f64 ? std::min(h->max_ct, 16) : h->max_ct));
     const int ncc = (r.C + ct - 1) / ct;
     // One launch for the whole call (voxelize_direct_kernel) when the per-workgroup atom scan is cheap next to the
     // slab's stores: per-molecule forward() calls, and batches of small molecules. Bigger jobs amortise the binning

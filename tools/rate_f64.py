@@ -12,7 +12,7 @@ if len(sys.argv) > 3:  # another build of the library (A/B)
     _l.LIB_PATH = os.path.abspath(sys.argv[3])
 import molvoxel_amd
 
-B, N, D, C = (int(sys.argv[1]) if len(sys.argv) > 1 else 8), 4000, 64, 32
+B, N, D, C = (int(sys.argv[1]) if len(sys.argv) > 1 else 8), 4000, 64, int(os.environ.get("F64_C", "32"))
 rng = np.random.default_rng(0)
 W = 0.5 * (D - 1)
 coords = rng.uniform(-W / 2, W / 2, (B * N, 3))
