@@ -116,6 +116,68 @@ def load_pmc_traffic(molecules_per_launch: int):
     return None
 
 
+def measure_pmc_traffic(batch: int, budget_s: float = 150.0):
+    """HBM bytes per voxelize launch, MEASURED for this run: two child processes, `rocprofv3 --pmc WRITE_SIZE` and
+    `--pmc FETCH_SIZE` (separate passes: the two counters do not fit one) over `bench.py --traffic-probe` - the same
+    launch on the same inputs, a few steps, no output. Collected and corrected as MI355X_MICROARCH.md prescribes
+    (counters in KB; FETCH_SIZE x 2 on gfx950). Children, not re-executions: this process keeps its GPU context.
+    Returns (bytes, detail) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    got = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    for counter in ("WRITE_SIZE", "FETCH_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", td, "--", sys.executable, os.path.abspath(__file__),
+                   "--traffic-probe", "--batch", str(batch)]
+            try:
+                res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=budget_s, text=True)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} pass exceeded {budget_s:.0f} s"
+            if res.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {res.returncode})"
+            vals = []
+            for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if "voxelize_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            vals.append(float(row["Counter_Value"]))
+            if len(vals) < 3:
+                return None, f"no {counter} rows for voxelize_kernel"
+            vals = vals[len(vals) // 2:]  # the later dispatches (warmed up)
+            got[counter] = sum(vals) / len(vals) * 1024.0
+    total = got["WRITE_SIZE"] + 2.0 * got["FETCH_SIZE"]
+    return total, (f"measured in this run: child rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE passes over bench.py --traffic-probe "
+                   f"(same launch, {batch} molecules); WRITE_SIZE {got['WRITE_SIZE']:.4g} B + 2 x FETCH_SIZE {got['FETCH_SIZE']:.4g} B "
+                   f"(gfx950 correction) per launch")
+
+
+def traffic_probe(args):
+    """--traffic-probe: the timed launch and nothing else (what measure_pmc_traffic profiles)."""
+    import torch
+
+    import molvoxel_amd
+
+    torch.cuda.set_device(0)
+    vox = molvoxel_amd.create_voxelizer(0.5, 64, "scalar", "gaussian", library="hip", device=0)
+    _, coords, feats = make_batch(args.batch, 0)
+    offsets = np.cumsum([0] + [c.shape[0] for c in coords]).astype(np.int64)
+    d_coords, d_feats = vox.asarray(np.concatenate(coords), "coords"), vox.asarray(np.concatenate(feats), "features")
+    out = vox.get_empty_grid(32, batch_size=args.batch)
+    for _ in range(8):
+        vox.forward_batch(d_coords, offsets, None, d_feats, 1.0, out_grid=out)
+    torch.cuda.synchronize()
+
+
 def make_cfg4_shard(total: int, rank: int, world: int):
     """cfg-4 (BASELINE.json configs[3]): `total` ligands (40-60 atoms, C = 16) cut into contiguous shards balanced by
     atom count (molvoxel_amd/sharding.py); returns this rank's molecules."""
@@ -280,6 +342,10 @@ def main():
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: mvx_set_overlap - the pre-pass of step k+1 runs under the voxelize launch of step k (the inputs "
                          "are HBM-resident and complete before the loop, which is that mode's contract); 0: serial calls")
+    ap.add_argument("--pmc-traffic", choices=("auto", "off"), default="auto",
+                    help="auto (N = 1, cfg2): measure roofline.traffic in this run with two child rocprofv3 --pmc passes "
+                         "(~30 s); if that is not possible, or off: the committed profiles/pmc_latest.json figure, labelled as replayed")
+    ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rehearse", action="store_true",
                     help="plumbing only: launcher, rendezvous, barrier, MAX, one JSON line - no GPU work, not a measurement")
     args = ap.parse_args()
@@ -299,6 +365,8 @@ def main():
         sys.exit(2)
     if args.rehearse:
         return rehearse(args, world, rank)
+    if args.traffic_probe:
+        return traffic_probe(args)
 
     # (RCCL between the ranks of one node needs dmabuf IPC on this driver stack; the pool exports this already)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -391,7 +459,17 @@ def main():
         k_ms = float(np.mean(k))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         ms_per_step = 1e3 * elapsed / args.steps
-        traffic = load_pmc_traffic(B // lps) if args.workload == "cfg2" else None
+        traffic, traffic_source = None, None
+        if args.workload == "cfg2":
+            why = "--pmc-traffic off"
+            if args.pmc_traffic == "auto" and args.gpus == 1 and lps == 1:
+                traffic, why = measure_pmc_traffic(B)
+                traffic_source = why if traffic is not None else None
+            if traffic is None:
+                traffic = load_pmc_traffic(B // lps)
+                if traffic is not None:
+                    traffic_source = ("profiles/pmc_latest.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this command on the "
+                                      f"builder's box; replayed here, not measured in this run: {why})")
         res = {
             "metric": "molecules/sec + achieved HBM GB/s, forward_features C=32 64^3 N=4000" if args.workload == "cfg2"
                       else "molecules/sec, batch of ligands (cfg-4), forward_features C=16 64^3 N~50",
@@ -439,9 +517,7 @@ def main():
                 "molecules_per_launch": B // lps,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "traffic": traffic,
-                "traffic_source": None if traffic is None else
-                                  "profiles/pmc_latest.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this command "
-                                  "on the builder's box; replayed here, not measured in this run)",
+                "traffic_source": traffic_source,
             },
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
             "parity_spot": spot,

@@ -16,7 +16,7 @@ WARMUP=${WARMUP:-20}
 PREWARM=$(python3 -c "import bench; print(bench.PREWARM_LAUNCHES)")
 # explicit --steps / --warmup: the slices below are derived from these, never from bench.py's defaults.
 # Dispatch order of one run: PREWARM pre-warm + WARMUP warm-up + STEPS timed (pass 1, `value`) + 2 + STEPS (pass 2, events)
-BENCH="python3 bench.py --cpu-seconds 0 --batch $BATCH --steps $STEPS --warmup $WARMUP"
+BENCH="python3 bench.py --cpu-seconds 0 --pmc-traffic off --batch $BATCH --steps $STEPS --warmup $WARMUP"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kernel_trace" -- $BENCH > "$out/kernel_trace.log" 2>&1 || echo "kernel-trace failed"
 i=0
 for grp in "WRITE_SIZE GRBM_GUI_ACTIVE" "FETCH_SIZE" \

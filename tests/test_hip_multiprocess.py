@@ -112,8 +112,19 @@ def test_bench_py_rccl_branch_with_one_rank():
     env["MVX_BENCH_COLLECTIVES"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--batch", "8", "--cpu-seconds", "0"]
+           "--batch", "8", "--cpu-seconds", "0", "--pmc-traffic", "off"]
     res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
     assert res.returncode == 0, res.stdout[-3000:]
     rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     assert rec["collective_backend"] == "nccl" and rec["ranks_seen"] == 1 and rec["parity_spot"] == "ok", rec.get("collective_note")
+
+
+def test_bench_py_measures_its_hbm_traffic_in_the_run():
+    """roofline.traffic of the N = 1 line: two child `rocprofv3 --pmc` passes (WRITE_SIZE, FETCH_SIZE) over the same
+    launch, in this run - not a figure replayed from profiles/."""
+    res = _bare_bench(["--steps", "2", "--warmup", "1", "--batch", "8", "--cpu-seconds", "0"])
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    rec = json.loads(res.stdout.splitlines()[-1])
+    rf = rec["roofline"]
+    assert rf["traffic_source"].startswith("measured in this run"), rf["traffic_source"]
+    assert 1.0 <= rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.25
