@@ -116,7 +116,7 @@ def load_pmc_traffic(molecules_per_launch: int):
     return None
 
 
-def measure_pmc_traffic(batch: int, budget_s: float = 150.0):
+def measure_pmc_traffic(batch: int, budget_s: float = 90.0):
     """HBM bytes per voxelize launch, MEASURED for this run: two child processes, `rocprofv3 --pmc WRITE_SIZE` and
     `--pmc FETCH_SIZE` (separate passes: the two counters do not fit one) over `bench.py --traffic-probe` - the same
     launch on the same inputs, a few steps, no output. Collected and corrected as MI355X_MICROARCH.md prescribes
@@ -131,6 +131,9 @@ def measure_pmc_traffic(batch: int, budget_s: float = 150.0):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
+    if any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) \
+            or any(k.startswith("ROCPROF") for k in os.environ):
+        return None, "this run is itself being profiled"
     got = {}
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
