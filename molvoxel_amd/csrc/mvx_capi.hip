@@ -605,6 +605,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     // 16-B stores need whole float4 groups per row (D % 4 == 0) and a 16-B aligned grid; anything else (odd
     // dimensions, a slice `grid[i]` of a batch grid whose slices are not 16-B multiples) takes the scalar-store path
     va.p.vec_store = (D % (f64 ? 2 : 4) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) ? 1 : 0;
+    va.p.xcd_ranges = (!f64 && !va.p.vec_store && sp.nzc == 1) ? 1 : 0;
     va.p.store_kind = h->store_kind;
     va.p.pace = (nslabs * (size_t)ncc > 4096) ? 1 : 0;
     va.p.sigma = h->cfg.sigma;
@@ -613,7 +614,12 @@ int run(mvx_handle *h, const RunArgs &r) {
 #endif
     // a sub-tile lies inside one reference block when its edges divide blockdim (or there is a single block):
     // the block cull is then wave-uniform and already folded into the candidate ranges.
-    const bool lane_range = !(g.nb == 1 || (g.bd % SUBX == 0 && g.bd % SUBY == 0 && g.bd % SUBZ == 0));
+    const bool lr_blocks = !(g.nb == 1 || (g.bd % SUBX == 0 && g.bd % SUBY == 0 && g.bd % SUBZ == 0));
+    // float32 grids whose rows are not whole 16-byte quads need the run-wise write-out (store_runs): compiled into the
+    // per-lane-range kernels and into voxelize_runs_kernel (the matrix-core walk of 32-channel chunks), nowhere else
+    const bool runs = !f64 && !va.p.vec_store;
+    const bool lane_range = lr_blocks || runs;
+    auto lane_range_for = [&](int32_t ct_) { return lr_blocks || (runs && !(ct_ == 32 && !chanwise)); };
 
     if (direct) {
         DirectArgs da;
@@ -678,7 +684,7 @@ int run(mvx_handle *h, const RunArgs &r) {
         if ((rc = prepass(k))) return rc;
     if (f64) { // float64 grids: one launch of the general slab loop over the whole batch
         for (int k = 0; k < nchunk && side_stream; ++k) HIP_TRY(hipStreamWaitEvent(s, overlap ? w.ev_pre : h->ev_pre[k], 0));
-        if ((rc = timed_launch(h, s, [&] { return launch_voxelize64(va, ct, gauss, chanwise, lane_range, s); }))) return rc;
+        if ((rc = timed_launch(h, s, [&] { return launch_voxelize64(va, ct, gauss, chanwise, lr_blocks, s); }))) return rc;
     } else {
         for (int k = 0; k < nchunk; ++k) {
             const int b0 = chunk_begin(k), b1 = chunk_begin(k + 1);
@@ -705,11 +711,11 @@ int run(mvx_handle *h, const RunArgs &r) {
             va.p.ncc = nfull;
             va.p.c0 = 0;
             // the bracket holds voxelize_kernel alone (what rocprofv3 reports under that name)
-            if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, ct, gauss, chanwise, lane_range, s); }))) return rc;
+            if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, ct, gauss, chanwise, lane_range_for(ct), s); }))) return rc;
             if (ct_rem) { // the remainder channels [nfull * ct, C) with a narrower kernel
                 va.p.ncc = 1;
                 va.p.c0 = nfull * ct;
-                if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, ct_rem, gauss, chanwise, lane_range, s); }))) return rc;
+                if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, ct_rem, gauss, chanwise, lane_range_for(ct_rem), s); }))) return rc;
             }
         }
     }

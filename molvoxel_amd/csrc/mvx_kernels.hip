@@ -1048,9 +1048,102 @@ __device__ __forceinline__ void accumulate_row(float2v (&acc)[(CT + 1) / 2], con
     }
 }
 
+// Write-out for grids whose rows are not whole 16-byte quads (D % 4 != 0, or a grid that is not 16-B aligned): the
+// float4-per-(row, z quad) stores below would be four 4-byte stores per lane at a 16-byte lane stride. Instead: a
+// (channel, x) plane's part of the slab is ONE contiguous run of the grid when the slab spans whole rows (nzc == 1: SUBY
+// rows of D floats = 800 B at D = 50), else one run per row segment. A run is written as 16-byte stores from its first
+// 16-B aligned float on, plus its <= 3 + 3 edge floats as 4-byte stores by other threads. The transposition tile holds
+// the runs as they lie in memory: run (c, x, y) at L0 + c * SC + x * SX + y * SY with the strides congruent mod 4 to
+// the grid's (D^3, D^2, D) and L0 to the first run's offset, so a 16-B aligned quad of the grid is a 16-B aligned quad of
+// the tile (one ds_read_b128 per store; reading four floats at a 16-byte lane stride is an 8-way bank conflict and cost
+// 20 % of the call). The strides never exceed the float4 layout's (RPC * RS, SUBY * RS, RS): same LDS allocation.
+// Plain stores, not non-temporal ones: the cache lines at both ends of a run are shared with the neighbouring slab's run,
+// and a line that stays in L2 until its second writer arrives goes to memory once, whole (VoxParams::xcd_ranges puts
+// the two writers behind the same L2). Measured, 64 molecules per call, TB/s of grid bytes (tools/odd_d_probe.py): D = 49
+// 2.18 -> 2.87, D = 63 2.76 -> 3.50, D = 64 on a grid 4 bytes off alignment 3.02 -> 3.62, D = 65 1.20 -> 2.32, D = 101
+// (C = 8) 1.01 -> 1.55 (4-byte stores at a 16-byte lane stride before). One 4-byte store per lane over consecutive floats
+// (no alignment cases at all) is slower than either: 1.6-2.0.
+struct RunLayout {
+    int SC, SX, SY; // tile floats between channels, x planes, rows
+    int joined;     // the slab spans whole rows: the rows of one (channel, x) follow each other in the grid (SY = D)
+    int run_len;    // floats per run
+    int ny, nx;     // rows / planes of the slab inside the grid
+    int seg;        // floats of a row inside the slab
+};
+__device__ __forceinline__ RunLayout run_layout(int NW, int x0, int y0, int z0, const VoxParams &P) {
+    RunLayout R;
+    const int D = P.D;
+    const unsigned D2 = (unsigned)D * (unsigned)D; // (low bits only are used)
+    R.joined = P.nzc == 1;
+    R.ny = min(SUBY, D - y0);
+    R.nx = min(SUBX, D - x0);
+    R.seg = R.joined ? D : min(SUBZ * NW, D - z0);
+    R.run_len = R.joined ? R.ny * D : R.seg;
+    R.SY = R.joined ? D : SUBZ * NW + ((D - SUBZ * NW) & 3);
+    R.SX = SUBY * R.SY + ((int)(D2 - (unsigned)(SUBY * R.SY)) & 3);
+    R.SC = ((SUBX * R.SX + 3) & ~3) + (int)((D2 * (unsigned)D) & 3u);
+    return R;
+}
+// offset of the tile's first run: congruent mod 4 to the 4-byte index of the run's first float in memory
+__device__ __forceinline__ int run_tile_origin(size_t S0, const float *out) {
+    return (int)(((unsigned)S0 + (unsigned)(reinterpret_cast<uintptr_t>(out) >> 2)) & 3u);
+}
+
+// `nch` tile channels starting at grid channel ch0 (S0: the first run's first float, floats from `out`); ZERO: zeros, no tile
+template <bool ZERO>
+__device__ __forceinline__ void store_runs(const float *tile, const RunLayout &R, int L0, int nch, int ch0, size_t S0, int tid,
+                                           int nthr, float *out, const VoxParams &P) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int D = P.D, run_len = R.run_len;
+    const int ry_sh = R.joined ? 0 : SUBY_SH; // runs per (channel, x): 1 | SUBY (rows beyond the grid are skipped)
+    const int nruns = (min(nch, P.C - ch0) << SUBX_SH) << ry_sh;
+    const size_t D2 = (size_t)D * D, D3 = D2 * D;
+    // run r = ((c * SUBX + x) << ry_sh) + yy: its first float in the grid and in the tile
+    auto locate = [&](int r, size_t &S, int &lbase) -> bool {
+        const int yy = r & ((1 << ry_sh) - 1), cx = r >> ry_sh, x = cx & (SUBX - 1), c = cx >> SUBX_SH;
+        S = S0 + (size_t)(unsigned)c * D3 + (size_t)((unsigned)x * (unsigned)D2 + (unsigned)(yy * D));
+        lbase = L0 + c * R.SC + x * R.SX + yy * R.SY;
+        return x < R.nx && yy < R.ny;
+    };
+    // 16-byte slots: thread -> (slot j of run rfirst, rfirst + rstep, ...), slots per run rounded up to a power of two
+    const int QS = run_len >> 2; // a run has QS or QS - 1 whole aligned quads
+    if (QS) {
+        const int qsh = 32 - __builtin_clz((unsigned)QS - 1u | 1u) - (QS == 1 ? 1 : 0); // ceil(log2(QS)); 2^qsh <= nthr
+        const int j = tid & ((1 << qsh) - 1), rstep = nthr >> qsh;
+        for (int r = tid >> qsh; r < nruns; r += rstep) {
+            size_t S;
+            int lbase;
+            const bool ok = locate(r, S, lbase);
+            const int i0 = ((4 - lbase) & 3) + 4 * j; // (floats before the run's first aligned one) + 4 j
+            if (ok && i0 + 4 <= run_len) {
+                f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (!ZERO) v = *reinterpret_cast<const f4 *>(tile + lbase + i0);
+                *reinterpret_cast<f4 *>(out + S + i0) = v;
+            }
+        }
+    }
+    // edge floats: thread e takes float k = e % 8 (< 6) of run e / 8 - k < 3: before the first aligned float; else after the
+    // last whole quad
+    for (int e = tid; e < nruns * 8; e += nthr) {
+        const int r = e >> 3, k = e & 7;
+        size_t S;
+        int lbase;
+        const bool ok = locate(r, S, lbase);
+        const int a = min((4 - lbase) & 3, run_len);
+        const int nfull = (run_len - a) >> 2;
+        const int i = k < 3 ? k : a + 4 * nfull + (k - 3);
+        if (ok && k < 6 && (k < 3 ? k < a : i < run_len)) {
+            const float v = ZERO ? 0.0f : tile[lbase + i];
+            out[S + i] = v;
+        }
+    }
+}
+
 // Write-out of one slab. `any` false: zero fill without the LDS round trip. Begins with a barrier (the union region
 // may still hold candidate rows) and ends without one.
-template <int CT, int CRMAX = MVX_CR>
+// RUNS: the kernel also serves grids whose rows are not whole 16-byte quads (store_runs). Only the per-lane-range kernels
+// are compiled with it (the host sends such grids there): the aligned-grid kernels keep their register budget.
+template <int CT, bool RUNS, int CRMAX = MVX_CR>
 __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], bool any, float *tile, int tid, int lane,
                                            int wave, int NW, int b, int cbase, int x0, int y0, int z0, float *out,
                                            const VoxParams &P) {
@@ -1072,19 +1165,17 @@ __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], b
         // 6.2 -> 6.7 TB/s (sleep 16 / 32 / 48 / 64 / 80 / 100: +0.9 / 2.8 / 4.7 / 7.5 / 7.0 / 3.7 %).
         // (only when several rounds of workgroups follow each other; a small launch would just start later)
         if (P.pace) __builtin_amdgcn_s_sleep(64);
+        if (RUNS && !P.vec_store) {
+            const RunLayout R = run_layout(NW, x0, y0, z0, P);
+            const size_t S0 = (((size_t)b * P.C + cbase) * D + x0) * D2 + (size_t)y0 * D + z0;
+            store_runs<true>(nullptr, R, run_tile_origin(S0, out), CT, cbase, S0, tid, NW * 64, out, P);
+            return;
+        }
         if (vox_ok) {
 #pragma unroll
             for (int p = 0; p < (CT + 3) / 4; ++p) {
                 const int c = cfirst + 4 * p;
-                if (c < CT && cbase + c < P.C) {
-                    float *dst = dst0 + (size_t)(4 * p) * D3;
-                    if (P.vec_store) {
-                        store_f4(dst, make_float4(0.f, 0.f, 0.f, 0.f), P.store_kind);
-                    } else {
-                        for (int k = 0; k < 4; ++k)
-                            if (zq + k < D) dst[k] = 0.0f;
-                    }
-                }
+                if (c < CT && cbase + c < P.C) store_f4(dst0 + (size_t)(4 * p) * D3, make_float4(0.f, 0.f, 0.f, 0.f), P.store_kind);
             }
         }
         return;
@@ -1092,6 +1183,28 @@ __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], b
     const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1), lx = lane >> (SUBZ_SH + SUBY_SH);
     const int col = SUBZ * wave + lz;
     const int rxy = lx * SUBY + ly;
+    if (RUNS && !P.vec_store) { // rows that are not whole 16-byte quads: the tile holds the slab's runs as they lie in memory (store_runs)
+        const RunLayout R = run_layout(NW, x0, y0, z0, P);
+        const size_t S0 = (((size_t)b * P.C + cbase) * D + x0) * D2 + (size_t)y0 * D + z0;
+        const bool zok = !R.joined || col < D; // (packed rows: a voxel beyond the row would land in the next row)
+        const int mine = lx * R.SX + ly * R.SY + col;
+#pragma unroll
+        for (int rd = 0; rd < NROUND; ++rd) {
+            const size_t S0r = S0 + (size_t)(rd * CR) * D3;
+            const int L0 = run_tile_origin(S0r, out);
+            __syncthreads();
+            if (zok) {
+#pragma unroll
+                for (int c = 0; c < CR; ++c) {
+                    const int cg = rd * CR + c;
+                    tile[L0 + c * R.SC + mine] = (cg & 1) ? acc[cg / 2].y : acc[cg / 2].x;
+                }
+            }
+            __syncthreads();
+            store_runs<false>(tile, R, L0, CR, cbase + rd * CR, S0r, tid, NW * 64, out, P);
+        }
+        return;
+    }
 #pragma unroll
     for (int rd = 0; rd < NROUND; ++rd) {
         __syncthreads(); // candidate rows (round 0) / previous tile (later rounds) fully consumed
@@ -1110,14 +1223,7 @@ __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], b
                 const int c = cfirst + 4 * p; // channel inside the round
                 if (c < CR && cbase + rd * CR + c < P.C) {
                     const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 4 * RPC * p) * RS + 4 * q);
-                    float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
-                    if (P.vec_store) {
-                        store_f4(dst, v, P.store_kind);
-                    } else {
-                        const float e4[4] = {v.x, v.y, v.z, v.w};
-                        for (int k = 0; k < 4; ++k)
-                            if (zq + k < D) dst[k] = e4[k];
-                    }
+                    store_f4(dst0 + (size_t)(rd * CR + 4 * p) * D3, v, P.store_kind);
                 }
             }
         }
@@ -1235,6 +1341,7 @@ __device__ __forceinline__ void accumulate_row64(double (&acc)[CT], const unsign
 // registers, no LDS transposition).
 template <int CT_, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
 struct OpsF32 {
+    static constexpr bool RUNS = LANE_RANGE; // carries the run-wise write-out (store_runs)
     static constexpr int CT = CT_;
     static constexpr bool GROUPED = false;
     typedef float2v Acc[(CT + 1) / 2];
@@ -1263,7 +1370,7 @@ struct OpsF32 {
     }
     static __device__ __forceinline__ void write(const Acc &acc, bool any, unsigned *un, int tid, int lane, int wave, int NW,
                                                  int b, const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
-        write_slab<CT>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
+        write_slab<CT, LANE_RANGE>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
                        static_cast<float *>(out), P);
     }
     // per-molecule launches (voxelize_direct_kernel): 16 channels per round - two rounds, four barriers; the small
@@ -1271,7 +1378,7 @@ struct OpsF32 {
     // single call 21.2 -> 20.4 us)
     static __device__ __forceinline__ void write_wide(const Acc &acc, bool any, unsigned *un, int tid, int lane, int wave, int NW,
                                                       int b, const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
-        write_slab<CT, DIRECT_CR>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
+        write_slab<CT, LANE_RANGE, DIRECT_CR>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
                                   static_cast<float *>(out), P);
     }
 };
@@ -1302,9 +1409,10 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int MX_CR = 8; // channels per write-out round of the matrix-core path
 size_t voxelize_mx_lds_bytes(int32_t NW) { return voxelize_rounds_lds_bytes(32, NW, MX_CR); }
 
-template <bool GAUSS, bool LANE_RANGE, bool GROUPED_ = false>
+template <bool GAUSS, bool LANE_RANGE, bool GROUPED_ = false, bool RUNS_ = LANE_RANGE>
 struct OpsMx32 {
     static constexpr int CT = 32;
+    static constexpr bool RUNS = RUNS_; // carries the run-wise write-out (store_runs)
     static constexpr bool GROUPED = GROUPED_;
     struct Acc {
         f16v p0, p1; // the x0 plane and the x0 + 1 plane of the sub-tile
@@ -1398,7 +1506,7 @@ struct OpsMx32 {
         float *out = static_cast<float *>(out_);
         if (!any) { // zero fill without the LDS round trip: the one-voxel-per-lane code (no accumulator is read)
             float2v zero[16];
-            write_slab<32>(zero, false, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0, out, P);
+            write_slab<32, RUNS>(zero, false, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0, out, P);
             return;
         }
         float *tile = reinterpret_cast<float *>(un);
@@ -1432,18 +1540,34 @@ struct OpsMx32 {
                     const int c = cfirst + 4 * p; // channel inside the round
                     if (c < CR && L.cbase + rd * CR + c < P.C) {
                         const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + 4 * RPC * p) * RS + 4 * q);
-                        float *dst = dst0 + (size_t)(rd * CR + 4 * p) * D3;
-                        if (P.vec_store) {
-                            store_f4(dst, v, P.store_kind);
-                        } else {
-                            const float e4[4] = {v.x, v.y, v.z, v.w};
-                            for (int k = 0; k < 4; ++k)
-                                if (zq + k < D) dst[k] = e4[k];
-                        }
+                        store_f4(dst0 + (size_t)(rd * CR + 4 * p) * D3, v, P.store_kind);
                     }
                 }
             }
         };
+        if (RUNS && !P.vec_store) { // rows that are not whole 16-byte quads: the tile holds the slab's runs as they lie in memory
+            const RunLayout R = run_layout(NW, x0, y0, z0, P);
+            const size_t S0 = (((size_t)b * P.C + L.cbase) * D + x0) * D2 + (size_t)y0 * D + z0;
+            const int col = SUBZ * wave + lz;
+            const bool zok = !R.joined || col < D;
+            const int mine_r = 4 * h * R.SC + ly * R.SY + col; // + c * SC + x * SX
+#pragma unroll
+            for (int rd = 0; rd < NROUND; ++rd) {
+                const size_t S0r = S0 + (size_t)(rd * CR) * D3;
+                const int L0 = run_tile_origin(S0r, out);
+                __syncthreads();
+                if (zok) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        tile[L0 + mine_r + c * R.SC] = acc.p0[4 * rd + c];
+                        tile[L0 + mine_r + c * R.SC + R.SX] = acc.p1[4 * rd + c];
+                    }
+                }
+                __syncthreads();
+                store_runs<false>(tile, R, L0, CR, L.cbase + rd * CR, S0r, tid, NW * 64, out, P);
+            }
+            return;
+        }
         typedef std::integral_constant<int, 0> R0;
         typedef std::integral_constant<int, 1> R1;
         typedef std::integral_constant<int, 2> R2;
@@ -1521,6 +1645,7 @@ size_t voxelize_mx64_lds_bytes(int32_t NW) {
 
 template <bool GAUSS, bool LANE_RANGE>
 struct OpsMx64 {
+    static constexpr bool RUNS = false;
     static constexpr int CT = 32;
     static constexpr bool GROUPED = false;
     struct Acc {
@@ -1658,6 +1783,7 @@ struct OpsMx64 {
 
 template <int CT_, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
 struct OpsF64 {
+    static constexpr bool RUNS = false;
     static constexpr int CT = CT_;
     typedef double Acc[CT];
     static constexpr int WORDS = 2;
@@ -1910,6 +2036,20 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
                     const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
                     const VoxParams P) {
     typedef typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE, GROUPED>::type Ops;
+#include "mvx_slab_body.inc"
+}
+
+// 32-channel chunks of float32 grids whose rows are not whole 16-byte quads (odd dimensions, unaligned grid slices): the
+// matrix-core walk with the run-wise write-out (store_runs). A kernel of its own: compiled into voxelize_kernel<32, ...>
+// the extra write-out path costs the aligned-grid kernels six more spilled registers and 0.5 % of the headline rate.
+template <bool GAUSS, int MAXT>
+__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
+    voxelize_runs_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
+                         const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc,
+                         float *__restrict__ out, const VoxParams P) {
+    typedef OpsMx32<GAUSS, false, false, true> Ops;
+    constexpr int CT = 32;
+    constexpr bool CHANWISE = false, GROUPED = false;
 #include "mvx_slab_body.inc"
 }
 
@@ -2580,6 +2720,13 @@ static void launch_profiled(K kern, dim3 grid, dim3 block, size_t lds, hipStream
     else hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
 }
 
+// blocks per molecule of the slab kernels
+static unsigned slab_grid_x(const VoxParams &p) {
+    const unsigned T = (unsigned)(p.nzc * p.nsy * p.nsx);
+    if (p.xcd_ranges) return 8u * ((T + 7u) / 8u); // (mvx_slab_body.inc: every XCD a contiguous range of slabs)
+    return T;
+}
+
 template <typename Ops, int MAXT = 1024, int WPE = 1>
 static hipError_t launch_dense(const VoxArgs &a, size_t lds, unsigned grid, unsigned total, hipStream_t s) {
     static LdsLimit raised;
@@ -2591,6 +2738,11 @@ static hipError_t launch_dense(const VoxArgs &a, size_t lds, unsigned grid, unsi
     launch_profiled(kern, dim3(grid), dim3(p.NW * 64), lds, s, a.rec, a.w, a.xlist, a.slist, a.slist_ext, a.offsets, a.n_one, a.Tc, a.kc,
                     a.out, a.p, (unsigned)(p.nzc * p.nsy * p.nsx), total);
     return hipGetLastError();
+}
+
+template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
+constexpr bool mx_kernel() {
+    return std::is_same<typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE, false>::type, OpsMx32<GAUSS, LANE_RANGE, false>>::value;
 }
 
 struct GroupedFn {
@@ -2611,7 +2763,7 @@ struct GroupedFn {
             auto kern = &voxelize_kernel<CT, GAUSS, false, LANE_RANGE, MAXT, true>;
             hipError_t e = raise_lds_limit(kern, main_lds + 16 * CHAN_GROUP_SLOTS, raised);
             if (e != hipSuccess) return e;
-            launch_profiled(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), main_lds + 16 * CHAN_GROUP_SLOTS, s, a.rec, a.w,
+            launch_profiled(kern, dim3(slab_grid_x(p), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), main_lds + 16 * CHAN_GROUP_SLOTS, s, a.rec, a.w,
                             a.slist, a.slist_ext, a.Tc, a.kc, static_cast<float *>(a.out), p);
             return hipGetLastError();
         }
@@ -2628,12 +2780,30 @@ struct LaunchFn {
         if (nb <= 0) return hipSuccess;
         if ((long long)nb * p.ncc > 65535) return hipErrorInvalidConfiguration;
         static LdsLimit raised;
-        const bool mx = std::is_same<typename SlabOps<CT, GAUSS, CHANWISE, LANE_RANGE, false>::type, OpsMx32<GAUSS, LANE_RANGE, false>>::value;
+        constexpr bool mx = mx_kernel<CT, GAUSS, CHANWISE, LANE_RANGE>();
         const size_t lds = mx ? voxelize_mx_lds_bytes(p.NW) : voxelize_rounds_lds_bytes(CT, p.NW, MVX_CR);
         auto kern = &voxelize_kernel<CT, GAUSS, CHANWISE, LANE_RANGE, MAXT>;
-        hipError_t e = raise_lds_limit(kern, lds, raised);
+        LdsLimit *state = &raised;
+        if (!p.vec_store) {
+            if constexpr (mx) {
+                static LdsLimit raised_runs;
+                kern = &voxelize_runs_kernel<GAUSS, MAXT>;
+                state = &raised_runs;
+            } else if (!LANE_RANGE) {
+                return hipErrorInvalidConfiguration; // (only the per-lane-range kernels carry store_runs)
+            }
+        }
+        hipError_t e = raise_lds_limit(kern, lds, *state);
         if (e != hipSuccess) return e;
-        launch_profiled(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), lds, s, a.rec, a.w,
+#ifdef MVX_MOLMIX
+        if (p.ncc == 1 && nb % MVX_MOLMIX == 0) {
+            launch_profiled(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx * MVX_MOLMIX), (unsigned)(nb / MVX_MOLMIX)), dim3(p.NW * 64), lds, s,
+                            a.rec, a.w, a.slist, a.slist_ext, a.Tc, a.kc, static_cast<float *>(a.out), a.p);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+#endif
+        launch_profiled(kern, dim3(slab_grid_x(p), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), lds, s, a.rec, a.w,
                         a.slist, a.slist_ext, a.Tc, a.kc, static_cast<float *>(a.out), a.p);
         return hipGetLastError();
     }
@@ -2719,7 +2889,7 @@ static hipError_t launch_mx64(const VoxArgs &a, hipStream_t s) {
     for (int m0 = 0; m0 < p.B; m0 += per) {
         p.b0 = m0;
         const int nb = p.B - m0 < per ? p.B - m0 : per;
-        launch_profiled(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), lds, s, a.rec, a.w, a.slist,
+        launch_profiled(kern, dim3(slab_grid_x(p), (unsigned)(nb * p.ncc)), dim3(p.NW * 64), lds, s, a.rec, a.w, a.slist,
                         a.slist_ext, static_cast<double *>(a.out), p);
         e = hipGetLastError();
         if (e != hipSuccess) return e;

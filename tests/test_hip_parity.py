@@ -1047,3 +1047,66 @@ def test_non_finite_and_huge_coordinates_never_contribute(mv):
         r_ok = radii if np.isscalar(radii) else v.asarray(radii[keep], "radii")
         clean = v.forward_features(v.asarray(xyz[keep], "coords"), None, v.asarray(f[keep], "features"), r_ok)
         assert torch.equal(outs[0], clean)
+
+
+@pytest.mark.parametrize("D,C_,shift", [(1, 1, 0), (2, 3, 1), (3, 32, 2), (5, 32, 3), (7, 33, 0), (31, 32, 1), (33, 64, 0),
+                                        (49, 32, 0), (50, 32, 2), (63, 40, 3), (64, 32, 1), (65, 32, 0), (66, 8, 2), (71, 16, 1),
+                                        (101, 4, 3)])
+@pytest.mark.parametrize("density", ["gaussian", "binary"])
+def test_run_wise_write_out_of_rows_that_are_not_whole_quads(mv, D, C_, shift, density):
+    """Grids with D % 4 != 0, or whose first float is not 16-byte aligned (`shift` floats into an aligned buffer), are
+    written run by run (store_runs: aligned 16-byte stores inside each contiguous run, 4-byte stores at its ends; whole-row
+    slabs up to D = 64, one run per row segment beyond). A batch of two molecules into a buffer with guard floats on both
+    sides: both grids equal the oracle's, the guards stay untouched. 32-channel chunks take voxelize_runs_kernel, the
+    remainder chunk and narrower grids the per-lane-range kernels."""
+    import torch
+
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(1000 * D + C_)
+    W_ = 0.5 * (D - 1)
+    n = min(600, 40 + 3 * D * D)
+    v = mv.create_voxelizer(0.5, D, "scalar", density, "hip")
+    mols = [(rng.uniform(-W_ / 2 - 1, W_ / 2 + 1, (n, 3)), rng.random((n, C_)).astype(np.float32)) for _ in range(2)]
+    per = C_ * D**3
+    guard = 64
+    flat = torch.full((guard + shift + 2 * per + guard,), 7.0, dtype=torch.float32, device=v.device)
+    grid = flat[guard + shift:guard + shift + 2 * per].view(2, C_, D, D, D)
+    coords = v.asarray(np.concatenate([m[0] for m in mols]), "coords")
+    feats = v.asarray(np.concatenate([m[1] for m in mols]), "features")
+    got = v.forward_batch(coords, np.array([0, n, 2 * n], dtype=np.int64), None, feats, 1.2, out_grid=grid)
+    assert got.data_ptr() == grid.data_ptr()
+    out = grid.cpu().numpy()
+    for b, (xyz, f) in enumerate(mols):
+        ref = c_oracle.voxelize(xyz, f, 1.2, dimension=D, density=density)
+        if density == "binary":
+            assert_exact(out[b], ref)
+        else:
+            assert_gaussian(out[b], ref)
+    host = flat.cpu().numpy()
+    assert (host[:guard + shift] == 7.0).all() and (host[guard + shift + 2 * per:] == 7.0).all()
+    # the same molecules one by one (the one-launch route where it applies), into the slices of the same buffer
+    flat.fill_(7.0)
+    for route in (0, 1):
+        v.debug_option("direct", route)
+        for b, (xyz, f) in enumerate(mols):
+            v.forward(v.asarray(xyz, "coords"), None, v.asarray(f, "features"), 1.2, out_grid=grid[b])
+        assert np.array_equal(grid.cpu().numpy(), out)
+    host = flat.cpu().numpy()
+    assert (host[:guard + shift] == 7.0).all() and (host[guard + shift + 2 * per:] == 7.0).all()
+
+
+@pytest.mark.parametrize("D", [30, 49, 70])
+def test_channel_wise_features_on_a_grid_of_odd_rows(mv, D):
+    """Channel-wise radii grouped by radius (the grouped matrix-core launch) on grids written run by run."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(D)
+    W_ = 0.5 * (D - 1)
+    n, C_ = 300, 12
+    xyz = rng.uniform(-W_ / 2, W_ / 2, (n, 3))
+    f = rng.random((n, C_)).astype(np.float32)
+    radii = np.repeat(np.float32([0.9, 1.3, 1.1]), 4)
+    v = mv.create_voxelizer(0.5, D, "channel-wise", "gaussian", "hip", output="numpy")
+    out = v.forward(xyz, None, f, radii)
+    assert_gaussian(out, c_oracle.voxelize(xyz, f, radii, dimension=D, radii_type="channel-wise"))

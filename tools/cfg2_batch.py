@@ -34,4 +34,5 @@ torch.cuda.synchronize()
 el = (time.perf_counter() - t0) / 40
 k = np.array(vox.read_kernel_times_ms())
 ab = wl.algorithmic_bytes(0) * B
-print(f"cfg-2 x {B} {' '.join(sys.argv[2:])}: kernel {np.median(k)*1e3:.1f} us ({ab/np.median(k)/1e9/8:.3f} of peak), step {el*1e3:.4f} ms ({ab/el/8e12:.3f})")
+sumtxt = f"  checksum {int(out.view(torch.int32).to(torch.int64).sum().item())}" if os.environ.get("SUM") else ""  # (A/B builds must agree bit for bit)
+print(f"cfg-2 x {B} {' '.join(sys.argv[2:])}: kernel {np.median(k)*1e3:.1f} us ({ab/np.median(k)/1e9/8:.3f} of peak), step {el*1e3:.4f} ms ({ab/el/8e12:.3f}){sumtxt}")

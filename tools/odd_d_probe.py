@@ -1,0 +1,51 @@
+"""Grids whose rows are not whole 16-byte quads (D % 4 != 0), and unaligned grid base addresses: whole-call rate next to the
+neighbouring aligned sizes (cfg-2 density: 4000 atoms at D = 64, scaled by volume; 64 molecules per call).
+    python3 tools/odd_d_probe.py [lib]"""
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 1:
+    from molvoxel_amd.voxelizer.hip import _lib as _l
+    _l.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), sys.argv[1])
+import molvoxel_amd
+
+B = 64
+rng = np.random.default_rng(0)
+
+
+def run(D, C=32, shift=0, empty=False, nw=0):
+    N = 8 if empty else max(8, int(4000 * (D / 64.0) ** 3))
+    vox = molvoxel_amd.create_voxelizer(0.5, D, library="hip")
+    if nw:
+        vox.debug_option("nw", nw)
+    W = 0.5 * (D - 1)
+    coords = vox.asarray(rng.uniform(-W / 2, W / 2, (B * N, 3)), "coords")
+    chan = vox.asarray(rng.random((B * N, C)).astype(np.float32), "features")
+    off = np.arange(B + 1, dtype=np.int64) * N
+    n = B * C * D**3
+    flat = torch.empty(n + 4, dtype=torch.float32, device="cuda")
+    out = flat[shift:shift + n].view(B, C, D, D, D)  # shift floats off the allocation's 16-B alignment
+    call = lambda: vox.forward_batch(coords, off, None, chan, 1.0, out_grid=out)
+    for _ in range(5):
+        call()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        call()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / 20
+    print(f"D = {D:3d} C = {C:2d} nw {nw:2d} base + {4 * shift:2d} B {'(8 atoms)' if empty else '':9s} {el * 1e3:8.3f} ms/call  {4 * n / el / 1e12:5.2f} TB/s of grid bytes")
+
+
+if os.environ.get("NW_SWEEP"):  # long rows cut into chunks of 8 sub-tiles (nw 0 = the plan) against balanced chunks
+    for D, C, nws in ((65, 32, (0, 5)), (66, 32, (0, 5)), (72, 32, (0, 5)), (80, 32, (0, 5)), (96, 16, (0, 6)), (100, 8, (0, 7)),
+                      (101, 8, (0, 7)), (104, 8, (0, 7)), (120, 8, (0, 8, 5)), (128, 8, (0, 6))):
+        for nw in nws:
+            run(D, C, nw=nw)
+    sys.exit(0)
+for D in (48, 49, 50, 51, 52, 63, 64, 65, 66):
+    run(D)
+run(64, shift=1)
+run(50, empty=True)
+run(100, C=8)
+run(101, C=8)
+run(102, C=8)
