@@ -340,18 +340,25 @@ int stage_inputs(mvx_handle *h, Workspace &w, const RunArgs &r, int64_t total, s
 // ---- 3. slab decomposition of the grid ------------------------------------------------------------------------------
 // slab = SUBX x SUBY x (SUBZ*NW) voxels, NW waves side by side along z. Whole rows (NW = row length in sub-tiles) up to
 // 8 waves; longer rows are cut into chunks of 8 sub-tiles (256-B runs).
+// whole_rows (the binned float32 pipeline): rows of 65 ... 128 voxels stay whole too (9 ... 16 waves, the 1024-thread
+// kernel variants, two or three workgroups per compute unit) unless D % 32 == 0. A row cut at 256 B leaves pieces that
+// share 64-byte blocks with their neighbours whenever rows are not multiples of 64 B - 16 molecules per call, C = 32,
+// TB/s of grid bytes, chunks -> whole rows: D = 72 1.80 -> 4.16, 88 1.94 -> 4.02, 104 2.12 -> 4.03, 120 2.25 -> 3.81,
+// 80 3.70 -> 4.12, 112 3.95 -> 4.02, 65 2.13 -> 2.57; D = 96 4.26 -> 4.28 and D = 128 5.13 -> 4.22 keep their chunks
+// (tools/odd_d_probe.py ROW_SWEEP=1, profiles/r03_odd_dimensions.txt).
 struct SlabPlan {
     int nsx, nsy, nzc, NW;
     size_t per_molecule() const { return (size_t)nsx * nsy * nzc; }
 };
 
-SlabPlan plan_slabs(const mvx_handle *h, int max_waves) {
+SlabPlan plan_slabs(const mvx_handle *h, int max_waves, bool whole_rows = false) {
     const int D = h->g.D;
     SlabPlan sp;
     sp.nsx = (D + SUBX - 1) / SUBX;
     sp.nsy = (D + SUBY - 1) / SUBY;
     const int nsz = (D + SUBZ - 1) / SUBZ;
     sp.NW = nsz <= max_waves ? nsz : max_waves;
+    if (whole_rows && nsz > max_waves && nsz <= 16 && D % 32 != 0) sp.NW = nsz;
     if (h->force_nw > 0 && h->force_nw <= 16) sp.NW = std::min(h->force_nw, nsz); // MVX_NW experiment knob
     sp.nzc = (nsz + sp.NW - 1) / sp.NW;
     return sp;
@@ -405,7 +412,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     // matrix-core slab kernel (voxelize64_kernel, 128 registers, two workgroups per unit): a.p.dcap == 0 selects it.
     const bool mx64 = f64 && r.C > MX64_MIN_C && !(r.radii_type == MVX_RADII_CHANNEL && r.mode == MODE_FEATURES) && h->max_ct64 >= 32 &&
                       h->max_ct >= 32 && h->force_nw == 0;
-    const SlabPlan sp = plan_slabs(h, 8);
+    SlabPlan sp = plan_slabs(h, 8);
     const int ct = mx64 ? 32 : pick_ct(std::min(r.C, f64 ? std::min(h->max_ct, 16) : h->max_ct));
     const int ncc = (r.C + ct - 1) / ct;
     // One launch for the whole call (voxelize_direct_kernel) when the per-workgroup atom scan is cheap next to the
@@ -419,6 +426,8 @@ int run(mvx_handle *h, const RunArgs &r) {
             direct = wgs <= DIRECT_MAX_WORKGROUPS && (long long)ncc * (long long)sp.per_molecule() * total <= DIRECT_MAX_ATOM_TESTS;
         }
     }
+
+    if (!f64 && !direct) sp = plan_slabs(h, 8, true);
 
     // Channel counts that are not a multiple of the chunk width (C = 33 ... 63, 65 ...): the binned float32 pipeline runs
     // the full chunks with the wide kernel and the remainder with the narrowest kernel that holds it (C = 33: 32 + 1,

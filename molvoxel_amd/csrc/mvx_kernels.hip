@@ -2030,8 +2030,12 @@ struct SlabOps<32, GAUSS, false, true, true> {
 };
 #endif
 
+#ifndef MVX_BIG_WPE // waves per SIMD the 1024-thread variants (slabs of 9 ... 16 waves: whole rows of 65 ... 128 voxels) are compiled for -
+                    // 8: 64 registers, two or three workgroups per compute unit (D = 72 4.16 TB/s against 3.75 with 4: 128 registers, one)
+#define MVX_BIG_WPE 8
+#endif
 template <int CT, bool GAUSS, bool CHANWISE, bool LANE_RANGE, int MAXT, bool GROUPED = false>
-__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
+__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : MVX_BIG_WPE))
     voxelize_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
                     const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc, float *__restrict__ out,
                     const VoxParams P) {
@@ -2043,7 +2047,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
 // matrix-core walk with the run-wise write-out (store_runs). A kernel of its own: compiled into voxelize_kernel<32, ...>
 // the extra write-out path costs the aligned-grid kernels six more spilled registers and 0.5 % of the headline rate.
 template <bool GAUSS, int MAXT>
-__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : 4))
+__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : MVX_BIG_WPE))
     voxelize_runs_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
                          const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc,
                          float *__restrict__ out, const VoxParams P) {

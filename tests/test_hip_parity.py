@@ -1051,12 +1051,13 @@ def test_non_finite_and_huge_coordinates_never_contribute(mv):
 
 @pytest.mark.parametrize("D,C_,shift", [(1, 1, 0), (2, 3, 1), (3, 32, 2), (5, 32, 3), (7, 33, 0), (31, 32, 1), (33, 64, 0),
                                         (49, 32, 0), (50, 32, 2), (63, 40, 3), (64, 32, 1), (65, 32, 0), (66, 8, 2), (71, 16, 1),
-                                        (101, 4, 3)])
+                                        (101, 4, 3), (72, 32, 0), (88, 8, 0), (104, 33, 0), (120, 16, 0), (127, 5, 0), (128, 4, 0)])
 @pytest.mark.parametrize("density", ["gaussian", "binary"])
 def test_run_wise_write_out_of_rows_that_are_not_whole_quads(mv, D, C_, shift, density):
     """Grids with D % 4 != 0, or whose first float is not 16-byte aligned (`shift` floats into an aligned buffer), are
     written run by run (store_runs: aligned 16-byte stores inside each contiguous run, 4-byte stores at its ends; whole-row
-    slabs up to D = 64, one run per row segment beyond). A batch of two molecules into a buffer with guard floats on both
+    slabs up to D = 128 - 9 ... 16 waves per slab beyond 64 -, one run per row segment beyond; the aligned sizes above 64
+    in the list cover the same slab plans with the float4 write-out). A batch of two molecules into a buffer with guard floats on both
     sides: both grids equal the oracle's, the guards stay untouched. 32-channel chunks take voxelize_runs_kernel, the
     remainder chunk and narrower grids the per-lane-range kernels."""
     import torch

@@ -8,7 +8,7 @@ if len(sys.argv) > 1:
     _l.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), sys.argv[1])
 import molvoxel_amd
 
-B = 64
+B = int(os.environ.get("BATCH", "64"))
 rng = np.random.default_rng(0)
 
 
@@ -40,6 +40,11 @@ if os.environ.get("NW_SWEEP"):  # long rows cut into chunks of 8 sub-tiles (nw 0
     for D, C, nws in ((65, 32, (0, 5)), (66, 32, (0, 5)), (72, 32, (0, 5)), (80, 32, (0, 5)), (96, 16, (0, 6)), (100, 8, (0, 7)),
                       (101, 8, (0, 7)), (104, 8, (0, 7)), (120, 8, (0, 8, 5)), (128, 8, (0, 6))):
         for nw in nws:
+            run(D, C, nw=nw)
+    sys.exit(0)
+if os.environ.get("ROW_SWEEP"):  # 64 < D <= 128: chunks of 8 sub-tiles (nw 0 = the plan) against whole rows in one slab
+    for D, C in ((72, 32), (80, 32), (88, 32), (96, 32), (104, 32), (112, 32), (120, 32), (128, 32), (65, 32), (100, 8), (72, 8), (72, 16), (88, 4), (120, 16)):
+        for nw in (0, 8, (D + 7) // 8):
             run(D, C, nw=nw)
     sys.exit(0)
 for D in (48, 49, 50, 51, 52, 63, 64, 65, 66):
