@@ -8,7 +8,7 @@ if len(sys.argv) > 1:
     _l.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), sys.argv[1])
 import molvoxel_amd
 
-B = int(os.environ.get("BATCH", "64"))
+B = int(os.environ.get("BATCH", "64"))  # molecules per call
 rng = np.random.default_rng(0)
 
 
@@ -33,7 +33,7 @@ def run(D, C=32, shift=0, empty=False, nw=0):
         call()
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / 20
-    print(f"D = {D:3d} C = {C:2d} nw {nw:2d} base + {4 * shift:2d} B {'(8 atoms)' if empty else '':9s} {el * 1e3:8.3f} ms/call  {4 * n / el / 1e12:5.2f} TB/s of grid bytes")
+    print(f"D = {D:3d} C = {C:2d} x {B:4d} nw {nw:2d} base + {4 * shift:2d} B {'(8 atoms)' if empty else '':9s} {el * 1e3:8.3f} ms/call  {4 * n / el / 1e12:5.2f} TB/s of grid bytes")
 
 
 if os.environ.get("NW_SWEEP"):  # long rows cut into chunks of 8 sub-tiles (nw 0 = the plan) against balanced chunks
@@ -41,6 +41,12 @@ if os.environ.get("NW_SWEEP"):  # long rows cut into chunks of 8 sub-tiles (nw 0
                       (101, 8, (0, 7)), (104, 8, (0, 7)), (120, 8, (0, 8, 5)), (128, 8, (0, 6))):
         for nw in nws:
             run(D, C, nw=nw)
+    sys.exit(0)
+if os.environ.get("SIZE_SWEEP"):  # aligned sizes up to 64, ~0.5 GB of grids per call
+    for D in (8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64):
+        for C in (32, 8):
+            B = max(8, min(4096, (1 << 29) // (C * D**3 * 4)))
+            run(D, C)
     sys.exit(0)
 if os.environ.get("ROW_SWEEP"):  # 64 < D <= 128: chunks of 8 sub-tiles (nw 0 = the plan) against whole rows in one slab
     for D, C in ((72, 32), (80, 32), (88, 32), (96, 32), (104, 32), (112, 32), (120, 32), (128, 32), (65, 32), (100, 8), (72, 8), (72, 16), (88, 4), (120, 16)):

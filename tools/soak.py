@@ -17,6 +17,10 @@ spec = importlib.util.spec_from_file_location("fz", "tests/test_hip_fuzz.py")
 fz = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(fz)
 import molvoxel_amd as mv
+import os
+
+if os.environ.get("SOAK_DIMS"):  # e.g. SOAK_DIMS=65,66,72,88,100,101,127: grid sizes outside the committed fuzz list
+    fz.DIMS = [int(x) for x in os.environ["SOAK_DIMS"].split(",")]
 
 if sys.argv[1] == "routes":
     import torch
@@ -100,6 +104,6 @@ for seed in range(first, first + count):
     if not ok:
         bad.append(seed)
         print("MISMATCH seed", seed, {k: v for k, v in case.items() if k not in ("xyz", "chan", "radii", "center")}, flush=True)
-    if (seed - first) % 200 == 199:
+    if (seed - first) % 50 == 49:
         print(f"{seed - first + 1} cases, {len(bad)} bad, {time.time() - t0:.0f}s", flush=True)
 print("done", count, "cases; bad seeds:", bad)
