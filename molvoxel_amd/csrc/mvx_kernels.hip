@@ -883,6 +883,10 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
 // LDS map (dynamic, 16-B aligned): voxelize_kernel: union { 64 x SW words of rows ; (CR*RPC rows) x RS floats tile };
 //   dense kernel: int list[LCAP] | uint32 zr[LCAP] | int nlist | union { dcap rows ; tile }, LCAP = 64 * min(NW, 4).
 
+#ifndef MVX_RSLEEP // OpsMx32::write: units of 64 cycles a wave waits after each write-out round of a paced slab
+#define MVX_RSLEEP 20
+#endif
+
 // 16-B output store: non-temporal. Output bytes are written once and never re-read here; nt keeps them from displacing
 // the re-read inputs in L2 (0.69 -> 0.54 ms, cfg-2; sc1 = plain). A/B builds (make EXPERIMENT=1) pick the kind at run
 // time - 0: plain (line stays in the XCD's L2); 1: nt; 2: sc1 (write-through); the shipped kernels hold one store form.
@@ -1501,7 +1505,7 @@ struct OpsMx32 {
             }
         }
     }
-    static __device__ __forceinline__ void write(const Acc &acc, bool any, unsigned *un, int tid, int lane, int wave, int NW,
+    static __device__ __forceinline__ void write(const Acc &acc, int any, unsigned *un, int tid, int lane, int wave, int NW,
                                                  int b, const LaneCtx &L, int x0, int y0, int z0, void *out_, const VoxParams &P) {
         float *out = static_cast<float *>(out_);
         if (!any) { // zero fill without the LDS round trip: the one-voxel-per-lane code (no accumulator is read)
@@ -1544,6 +1548,16 @@ struct OpsMx32 {
                     }
                 }
             }
+            // Pacing (any == 2: a slab of few candidates in a launch of many workgroups - the store-bound regime): the
+            // wave holds back ~1300 cycles after each round's stores, about the time a compute unit needs to drain the 16 KB
+            // a workgroup just queued. Left alone a workgroup pushes its 64 KB within ~2 kcycles and the row loads of the
+            // unit's other workgroups wait behind them. Same box, kernel, of peak: cfg-2 x 256 0.771-0.794 -> 0.807-0.811,
+            // cfg-5 x 8 0.697 -> 0.711; 256 / 1024 / 1536 / 1920 / 2560 cycles: +0.5 / +2.3 / +2.5 / +0.5 / -7 %. Slabs
+            // of more than MVX_PACE_MAX candidates are bound by their walk and lose by waiting (radius 1.5 A: -5 % when
+            // every slab is paced, +1 % with the limit at 48; 2.0 A: +2 %). Waiting for the stores' acknowledgement
+            // instead (s_waitcnt vmcnt(0)) gives +4 % where the sleep gives +4.7 %; a sleep after every store instruction,
+            // or waves starting their first round apart, the same or less (profiles/r03_round_pacing.txt).
+            if (rd < 3 && any == 2) __builtin_amdgcn_s_sleep(MVX_RSLEEP);
         };
         if (RUNS && !P.vec_store) { // rows that are not whole 16-byte quads: the tile holds the slab's runs as they lie in memory
             const RunLayout R = run_layout(NW, x0, y0, z0, P);
@@ -1736,7 +1750,7 @@ struct OpsMx64 {
     // Write-out through the float64 tile of write_slab64 ([channel][x, y row][z], CR64 = 8 channels per round). Round t
     // holds channels 8 t .. 8 t + 7 = channel block t / 2, i = 8 (t % 2) + 4 rr + lane / 16 with rr = 0, 1, i.e. registers
     // r = 2 (t % 2) + rr of every lane: each lane writes 2 channels x 4 voxels per round.
-    static __device__ __forceinline__ void write(const Acc &acc, bool, unsigned *un, int tid, int lane, int wave, int NW, int b,
+    static __device__ __forceinline__ void write(const Acc &acc, int any, unsigned *un, int tid, int lane, int wave, int NW, int b,
                                                  const LaneCtx &L, int x0, int y0, int z0, void *out_, const VoxParams &P) {
         double *out = static_cast<double *>(out_);
         double *tile = reinterpret_cast<double *>(un);
@@ -1777,6 +1791,9 @@ struct OpsMx64 {
                     }
                 }
             }
+            // (round pacing as in OpsMx32::write, measured here: -7 % at 1280 cycles per round, -11 % at 2560 - two
+            // workgroups per unit with a float64 walk between their write-outs do not queue loads behind stores)
+            (void)any;
         }
     }
 };
