@@ -883,6 +883,9 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
 // LDS map (dynamic, 16-B aligned): voxelize_kernel: union { 64 x SW words of rows ; (CR*RPC rows) x RS floats tile };
 //   dense kernel: int list[LCAP] | uint32 zr[LCAP] | int nlist | union { dcap rows ; tile }, LCAP = 64 * min(NW, 4).
 
+#ifndef MVX_EMPTY_SPLIT // write_slab: units of 64 cycles between the pieces of an empty slab's zero fill (paced launches)
+#define MVX_EMPTY_SPLIT 20
+#endif
 #ifndef MVX_RSLEEP // OpsMx32::write: units of 64 cycles a wave waits after each write-out round of a paced slab
 #define MVX_RSLEEP 20
 #endif
@@ -1180,6 +1183,11 @@ __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], b
             for (int p = 0; p < (CT + 3) / 4; ++p) {
                 const int c = cfirst + 4 * p;
                 if (c < CT && cbase + c < P.C) store_f4(dst0 + (size_t)(4 * p) * D3, make_float4(0.f, 0.f, 0.f, 0.f), P.store_kind);
+                // ... and the fill itself goes out in pieces of two store instructions (16 KB per workgroup) ~1300 cycles
+                // apart, like the write-out rounds of OpsMx32::write: ligand batches 6.55 -> 6.83 TB/s (0.85 of peak;
+                // 512 / 1024 / 1536 / 2048 cycles: +2 / +3.5 / +4.3 / +3.6 %; with a first wait of 2048 instead of 4096
+                // cycles: -1 / +1 %)
+                if (P.pace && (p & 1) && p + 1 < (CT + 3) / 4) __builtin_amdgcn_s_sleep(MVX_EMPTY_SPLIT);
             }
         }
         return;

@@ -4,6 +4,11 @@ import sys
 import numpy as np
 
 sys.path.insert(0, ".")
+import os
+
+if os.environ.get("LIB"):  # another build of the library (A/B): path relative to the repo root
+    from molvoxel_amd.voxelizer.hip import _lib as _l
+    _l.LIB_PATH = os.path.abspath(os.environ["LIB"])
 import bench_configs as bc
 from molvoxel_amd import workloads as W
 
