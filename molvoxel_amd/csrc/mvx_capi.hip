@@ -359,6 +359,13 @@ SlabPlan plan_slabs(const mvx_handle *h, int max_waves, bool whole_rows = false)
     const int nsz = (D + SUBZ - 1) / SUBZ;
     sp.NW = nsz <= max_waves ? nsz : max_waves;
     if (whole_rows && nsz > max_waves && nsz <= 16 && D % 32 != 0) sp.NW = nsz;
+    // longer rows that are not multiples of 64 B: as few, equally long chunks as 16 waves allow (every cut shares a 64-byte
+    // block between two workgroups) - D = 136 1.90 -> 2.10 TB/s, 152 2.28 -> 2.50, 168 2.01 -> 2.19, 200 (C = 16) 1.68 ->
+    // 1.89; multiples of 64 B keep chunks of 8 (D = 144 3.36 against 2.54-2.67, 160 3.60 against 2.81-3.15)
+    if (whole_rows && nsz > 16 && D % 16 != 0) {
+        const int k = (nsz + 15) / 16;
+        sp.NW = (nsz + k - 1) / k;
+    }
     if (h->force_nw > 0 && h->force_nw <= 16) sp.NW = std::min(h->force_nw, nsz); // MVX_NW experiment knob
     sp.nzc = (nsz + sp.NW - 1) / sp.NW;
     return sp;

@@ -1051,7 +1051,7 @@ def test_non_finite_and_huge_coordinates_never_contribute(mv):
 
 @pytest.mark.parametrize("D,C_,shift", [(1, 1, 0), (2, 3, 1), (3, 32, 2), (5, 32, 3), (7, 33, 0), (31, 32, 1), (33, 64, 0),
                                         (49, 32, 0), (50, 32, 2), (63, 40, 3), (64, 32, 1), (65, 32, 0), (66, 8, 2), (71, 16, 1),
-                                        (101, 4, 3), (72, 32, 0), (88, 8, 0), (104, 33, 0), (120, 16, 0), (127, 5, 0), (128, 4, 0)])
+                                        (101, 4, 3), (72, 32, 0), (88, 8, 0), (104, 33, 0), (120, 16, 0), (127, 5, 0), (128, 4, 0), (136, 2, 0), (150, 2, 1), (200, 1, 0)])
 @pytest.mark.parametrize("density", ["gaussian", "binary"])
 def test_run_wise_write_out_of_rows_that_are_not_whole_quads(mv, D, C_, shift, density):
     """Grids with D % 4 != 0, or whose first float is not 16-byte aligned (`shift` floats into an aligned buffer), are

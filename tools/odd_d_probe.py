@@ -48,6 +48,12 @@ if os.environ.get("SIZE_SWEEP"):  # aligned sizes up to 64, ~0.5 GB of grids per
             B = max(8, min(4096, (1 << 29) // (C * D**3 * 4)))
             run(D, C)
     sys.exit(0)
+if os.environ.get("LONG_SWEEP"):  # rows of more than 128 voxels: chunks of 8 sub-tiles (nw 0) against fewer, longer chunks
+    for D, C, nws in ((136, 32, (0, 9)), (144, 32, (0, 9, 16)), (152, 32, (0, 10)), (160, 32, (0, 10, 16)), (168, 32, (0, 11)),
+                      (192, 16, (0, 12, 16)), (200, 16, (0, 13)), (256, 8, (0, 16))):
+        for nw in nws:
+            run(D, C, nw=nw)
+    sys.exit(0)
 if os.environ.get("ROW_SWEEP"):  # 64 < D <= 128: chunks of 8 sub-tiles (nw 0 = the plan) against whole rows in one slab
     for D, C in ((72, 32), (80, 32), (88, 32), (96, 32), (104, 32), (112, 32), (120, 32), (128, 32), (65, 32), (100, 8), (72, 8), (72, 16), (88, 4), (120, 16)):
         for nw in (0, 8, (D + 7) // 8):
