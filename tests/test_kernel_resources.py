@@ -42,6 +42,26 @@ def test_batched_voxelize_kernels_fit_their_occupancy(res):
             assert r["vspill"] <= 16 and r["scratch"] <= 80, (name, r)
 
 
+def test_whole_row_slabs_of_long_rows_keep_two_workgroups_per_unit(res):
+    """Rows of 65 ... 128 voxels stay in one slab of 9 ... 16 waves (plan_slabs): the 1024-thread variants are compiled for
+    64 registers so that two or three such workgroups fit a compute unit (D = 72: 4.16 against 3.75 TB/s with 128)."""
+    ks = {k: v for k, v in res.items() if (k.startswith("voxelize_kernel<") and ", 1024, " in k) or k.startswith("voxelize_runs_kernel<")}
+    assert len(ks) >= 30
+    for name, r in ks.items():
+        assert r["vgpr"] <= 64, (name, r)
+    for name in ("voxelize_kernel<32, true, false, false, 1024, false>", "voxelize_kernel<32, false, false, false, 1024, false>"):
+        assert res[name]["scratch"] <= 32 and res[name]["vspill"] <= 6, (name, res[name])
+
+
+def test_run_wise_write_out_lives_in_its_own_kernels(res):
+    """store_runs (grids whose rows are not whole 16-byte quads) is compiled into voxelize_runs_kernel and the
+    per-lane-range variants only: inside the headline kernel it cost six more spilled registers and 0.5 % of its rate."""
+    for maxt in (512, 1024):
+        for gauss in ("true", "false"):
+            r = res[f"voxelize_runs_kernel<{gauss}, {maxt}>"]
+            assert r["vgpr"] <= 64 and r["vspill"] <= 12 and r["scratch"] <= 48, (gauss, maxt, r)
+
+
 def test_float64_matrix_core_kernel_keeps_two_workgroups_per_unit(res):
     for name, r in res.items():
         if name.startswith("voxelize64_kernel<"):
