@@ -2082,6 +2082,12 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : MVX_BIG_WPE))
 #include "mvx_slab_body.inc"
 }
 
+// (Measured and removed, round 3: channel counts of 32 k + r with the remainder chunk's workgroups - CTR vector-ALU
+// accumulators - in the SAME launch as the full chunks' (a kernel that branches on the chunk index into two inclusions of
+// the slab body). Bit-identical, and slower than the second launch it replaced: C = 33 0.618 against 0.580 ms per 64
+// molecules, C = 40 0.647 / 0.605, C = 48 0.708 / 0.652, C = 65 0.967 / 0.912 - the remainder's workgroups take slots from
+// the store-streaming ones for longer than their own launch lasts.)
+
 // float64 grids, chunks of 32 channels, scalar / atom-wise radii: the slab body with OpsMx64 (128 registers)
 template <bool GAUSS, bool LANE_RANGE, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 4 : 2))
