@@ -14,7 +14,8 @@
  *   - no ownership transfer: every buffer is caller-owned. Pointers are tagged host/device by
  *     the *_kind arguments (MVX_HOST / MVX_DEVICE). Device pointers must belong to the handle's
  *     device. A 16-byte aligned `out` with dimension % 4 == 0 gets 16-B stores; any other
- *     float-aligned `out` (e.g. slice i of a batch grid of odd dimension) is written with scalar stores.
+ *     float-aligned `out` (e.g. slice i of a batch grid of odd dimension) is written run by run: aligned
+ *     16-B stores inside each contiguous run of the grid, 4-B stores at its ends (float64 grids: 8-B stores).
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). With MVX_DEVICE
  *     outputs the call is asynchronous on that stream; with MVX_HOST outputs it returns after
  *     the copy back has completed.
