@@ -34,10 +34,12 @@ else:
     vox = molvoxel_amd.create_voxelizer(0.5, 64, library="hip")
     radii = float(os.environ.get("RADIUS", "1.0"))  # scalar radius in Angstrom (cfg-2 itself: 1.0)
     nwg = B * 512
+    vox.debug_option("direct", 0)
 coords = vox.asarray(np.concatenate(wl.coords[:B]), "coords")
-feats = vox.asarray(np.concatenate(wl.channels[:B]), "features")
+NCH = int(os.environ.get("CHANNELS", "32"))  # cfg-2 with fewer feature channels (1: forward_single, no features at all)
+feats = None if NCH == 1 else vox.asarray(np.concatenate(wl.channels[:B])[:, :NCH].copy(), "features")
 offsets = np.arange(B + 1, dtype=np.int64) * wl.coords[0].shape[0]
-out = vox.get_empty_grid(32, batch_size=B)
+out = vox.get_empty_grid(NCH if not CFG5 else 32, batch_size=B)
 for _ in range(25):
     vox.forward_batch(coords, offsets, None, feats, radii, out_grid=out)
 torch.cuda.synchronize()
