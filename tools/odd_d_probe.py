@@ -48,6 +48,11 @@ if os.environ.get("SIZE_SWEEP"):  # aligned sizes up to 64, ~0.5 GB of grids per
             B = max(8, min(4096, (1 << 29) // (C * D**3 * 4)))
             run(D, C)
     sys.exit(0)
+if os.environ.get("PACE_SWEEP"):  # aligned sizes with 32-channel chunks, ~2 GB of grids per call: where the round pacing applies
+    for D in (24, 32, 40, 48, 56, 64):
+        B = max(8, (1 << 31) // (32 * D**3 * 4))
+        run(D, 32)
+    sys.exit(0)
 if os.environ.get("LONG_SWEEP"):  # rows of more than 128 voxels: chunks of 8 sub-tiles (nw 0) against fewer, longer chunks
     for D, C, nws in ((136, 32, (0, 9)), (144, 32, (0, 9, 16)), (152, 32, (0, 10)), (160, 32, (0, 10, 16)), (168, 32, (0, 11)),
                       (192, 16, (0, 12, 16)), (200, 16, (0, 13)), (256, 8, (0, 16))):
