@@ -624,11 +624,12 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.xcd_ranges = (!f64 && !va.p.vec_store && sp.nzc == 1) ? 1 : 0;
     va.p.store_kind = h->store_kind;
     // 1: empty slabs hold their zero fill back and send it in pieces (launches of more than 4096 workgroups); 2: light slabs
-    // also pace their write-out rounds (OpsMx32::write) - launches of at least 24 576 workgroups (48 cfg-2 molecules): same
-    // box, cfg-2 kernel of peak, unpaced -> paced rounds: 16 molecules 0.734 -> 0.715, 32: 0.767 -> 0.745, 64: 0.773 -> 0.785,
-    // 128: 0.775 -> 0.801, 256: 0.768 -> 0.801 (profiles/r03_round_pacing.txt)
+    // also pace their write-out rounds (OpsMx32::write) - launches of at least 49 152 workgroups (96 cfg-2 molecules): same
+    // box, cfg-2 kernel of peak in sustained back-to-back calls, unpaced -> paced rounds: 16 molecules 0.734 -> 0.715, 32:
+    // 0.767 -> 0.745, 64: 0.773 -> 0.785, 128: 0.775 -> 0.801, 256: 0.768 -> 0.801; in short bursts on a cool GPU (25 calls)
+    // 64 molecules lose 3-5 % instead, hence the limit above them (profiles/r03_round_pacing.txt)
     const size_t wgs = nslabs * (size_t)ncc;
-    va.p.pace = wgs >= 24576 ? 2 : (wgs > 4096 ? 1 : 0);
+    va.p.pace = wgs >= 49152 ? 2 : (wgs > 4096 ? 1 : 0);
     va.p.sigma = h->cfg.sigma;
 #ifdef MVX_DIAG
     va.p.dbg = h->dbg;

@@ -1556,7 +1556,7 @@ struct OpsMx32 {
                     }
                 }
             }
-            // Pacing (any == 2: a slab of few candidates in a launch of at least 24 576 workgroups - the store-bound regime;
+            // Pacing (any == 2: a slab of few candidates in a launch of at least 49 152 workgroups - the store-bound regime;
             // smaller launches lose 2-3 % by it, mvx_capi.hip): the
             // wave holds back ~1300 cycles after each round's stores, about the time a compute unit needs to drain the 16 KB
             // a workgroup just queued. Left alone a workgroup pushes its 64 KB within ~2 kcycles and the row loads of the

@@ -55,7 +55,7 @@ run("forward_single", 64, "scalar", "gaussian", "single", 1, 1.0)
 run("features C=5", 64, "scalar", "gaussian", "features", 5, 1.0)
 run("features C=64", 64, "scalar", "gaussian", "features", 64, 1.0)
 run("features C=33", 64, "scalar", "gaussian", "features", 33, 1.0)
-run("D=50 (not a multiple of 4: scalar stores)", 50, "scalar", "gaussian", "features", 32, 1.0)
+run("D=50 (not a multiple of 4: run-wise write-out)", 50, "scalar", "gaussian", "features", 32, 1.0)
 run("D=48", 48, "scalar", "gaussian", "features", 32, 1.0)
 run("D=96", 96, "scalar", "gaussian", "features", 16, 1.0)
 run("blockdim=5 (sub-tiles straddle reference blocks)", 64, "scalar", "gaussian", "features", 32, 1.0, blockdim=5)
