@@ -42,6 +42,8 @@ else:
     C_ = wl.num_channels
 if os.environ.get("MVX_DBG"):  # diagnostic builds: run-time ablations of the direct kernel
     vox.debug_option("dbg", int(os.environ["MVX_DBG"]))
+if os.environ.get("MVX_MAX_CT"):  # narrower chunks: more, lighter workgroups per call
+    vox.debug_option("max_ct", int(os.environ["MVX_MAX_CT"]))
 if os.environ.get("MVX_DENSE_GRID"):
     vox.debug_option("dense_grid", int(os.environ["MVX_DENSE_GRID"]))
 grid = vox.get_empty_grid(C_)
