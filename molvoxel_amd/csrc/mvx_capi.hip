@@ -426,7 +426,10 @@ int run(mvx_handle *h, const RunArgs &r) {
     // slab's stores: per-molecule forward() calls, and batches of small molecules. Bigger jobs amortise the binning
     // pre-pass and take the three-launch pipeline.
     bool direct = false;
-    if (!f64 && sp.NW <= 8 && (long long)r.B * ncc <= 65535) {
+    // (whole-row slabs only, D <= 64: with rows cut in two the one-launch route loses to the binned pipeline at every size
+    // measured - one molecule per call, D = 68 / 72 / 76, us per call one launch / binned: 4000-atom-density pocket 57 / 23,
+    // 65 / 24, 69 / 27; 8 atoms 24 / 18, 26 / 19, 28 / 23; C = 8 48 / 20, 54 / 19, 58 / 22 - profiles/r03_odd_dimensions.txt)
+    if (!f64 && sp.NW <= 8 && sp.nzc == 1 && (long long)r.B * ncc <= 65535) {
         if (h->direct_mode >= 0) direct = h->direct_mode == 1;
         else {
             const long long wgs = (long long)r.B * ncc * (long long)sp.per_molecule();

@@ -17,6 +17,8 @@ def run(D, C=32, shift=0, empty=False, nw=0):
     vox = molvoxel_amd.create_voxelizer(0.5, D, library="hip")
     if nw:
         vox.debug_option("nw", nw)
+    if os.environ.get("DIRECT"):  # 0: the binned pipeline, 1: the one-launch route (where it applies)
+        vox.debug_option("direct", int(os.environ["DIRECT"]))
     W = 0.5 * (D - 1)
     coords = vox.asarray(rng.uniform(-W / 2, W / 2, (B * N, 3)), "coords")
     chan = vox.asarray(rng.random((B * N, C)).astype(np.float32), "features")
@@ -47,6 +49,12 @@ if os.environ.get("SIZE_SWEEP"):  # aligned sizes up to 64, ~0.5 GB of grids per
         for C in (32, 8):
             B = max(8, min(4096, (1 << 29) // (C * D**3 * 4)))
             run(D, C)
+    sys.exit(0)
+if os.environ.get("ONE_SWEEP"):  # one molecule per call, rows of 65 ... 96 voxels (BATCH=1 DIRECT=0|1)
+    for D in (64, 68, 72, 76, 80, 88, 96):
+        run(D, 32)
+        run(D, 32, empty=True)  # 8 atoms: a ligand-sized call
+        run(D, 8)
     sys.exit(0)
 if os.environ.get("PACE_SWEEP"):  # aligned sizes with 32-channel chunks, ~2 GB of grids per call: where the round pacing applies
     for D in (24, 32, 40, 48, 56, 64):
