@@ -62,6 +62,10 @@ constexpr long long DIRECT_MAX_WORKGROUPS = 1536;
 constexpr int MX64_MIN_C = MVX_MX64_MIN_C; // float64 grids of more channels than this take the matrix-core slab kernel
 // ... and of at most this many atom tests (every workgroup scans its molecule's atoms: ~2 us per million)
 constexpr long long DIRECT_MAX_ATOM_TESTS = 16ll << 20;
+// ... with several channel chunks (C > 32) every chunk's workgroups scan, stage and walk again: one molecule per call, C = 64,
+// us per call one launch / binned: D = 64 4000 atoms 33 / 26, D = 48 1700 atoms 24 / 20 (0.97 M tests), D = 32 500 atoms
+// 13 / 18 (0.13 M), 8 atoms 10-18 / 17-20 - the one-launch route only up to this many tests then
+constexpr long long DIRECT_MAX_ATOM_TESTS_CHUNKED = 400000;
 
 } // namespace
 
@@ -433,7 +437,8 @@ int run(mvx_handle *h, const RunArgs &r) {
         if (h->direct_mode >= 0) direct = h->direct_mode == 1;
         else {
             const long long wgs = (long long)r.B * ncc * (long long)sp.per_molecule();
-            direct = wgs <= DIRECT_MAX_WORKGROUPS && (long long)ncc * (long long)sp.per_molecule() * total <= DIRECT_MAX_ATOM_TESTS;
+            direct = wgs <= DIRECT_MAX_WORKGROUPS &&
+                     (long long)ncc * (long long)sp.per_molecule() * total <= (ncc > 1 ? DIRECT_MAX_ATOM_TESTS_CHUNKED : DIRECT_MAX_ATOM_TESTS);
         }
     }
 

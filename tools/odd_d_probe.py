@@ -56,6 +56,12 @@ if os.environ.get("ONE_SWEEP"):  # one molecule per call, rows of 65 ... 96 voxe
         run(D, 32, empty=True)  # 8 atoms: a ligand-sized call
         run(D, 8)
     sys.exit(0)
+if os.environ.get("ROUTE_SWEEP"):  # one molecule per call up to D = 64: is the route rule's choice the faster one? (BATCH=1, DIRECT unset / 0 / 1)
+    for D in (24, 32, 48, 49, 50, 63, 64):
+        for C in (1, 8, 32, 64):
+            run(D, C)
+            run(D, C, empty=True)
+    sys.exit(0)
 if os.environ.get("PACE_SWEEP"):  # aligned sizes with 32-channel chunks, ~2 GB of grids per call: where the round pacing applies
     for D in (24, 32, 40, 48, 56, 64):
         B = max(8, (1 << 31) // (32 * D**3 * 4))
