@@ -66,6 +66,11 @@ constexpr long long DIRECT_MAX_ATOM_TESTS = 16ll << 20;
 // us per call one launch / binned: D = 64 4000 atoms 33 / 26, D = 48 1700 atoms 24 / 20 (0.97 M tests), D = 32 500 atoms
 // 13 / 18 (0.13 M), 8 atoms 10-18 / 17-20 - the one-launch route only up to this many tests then
 constexpr long long DIRECT_MAX_ATOM_TESTS_CHUNKED = 400000;
+// ... and launches of more than 512 workgroups (two or three molecules per call) only up to this many: the scans of the
+// second and third molecule's workgroups run on the same compute units as the first's - us per call one launch / binned,
+// cfg-2 density: D = 64 C = 32 two molecules 35 / 27, three 47 / 33; C = 8 28 / 21, 40 / 24; D = 48 C = 16 two 22 / 18, four
+// 34 / 21; 8-atom molecules stay (18 / 20, 24 / 27 at C = 32) (profiles/r03_odd_dimensions.txt)
+constexpr long long DIRECT_MAX_ATOM_TESTS_MANY = 300000;
 
 } // namespace
 
@@ -437,8 +442,8 @@ int run(mvx_handle *h, const RunArgs &r) {
         if (h->direct_mode >= 0) direct = h->direct_mode == 1;
         else {
             const long long wgs = (long long)r.B * ncc * (long long)sp.per_molecule();
-            direct = wgs <= DIRECT_MAX_WORKGROUPS &&
-                     (long long)ncc * (long long)sp.per_molecule() * total <= (ncc > 1 ? DIRECT_MAX_ATOM_TESTS_CHUNKED : DIRECT_MAX_ATOM_TESTS);
+            const long long limit = ncc > 1 ? DIRECT_MAX_ATOM_TESTS_CHUNKED : (wgs <= 512 ? DIRECT_MAX_ATOM_TESTS : DIRECT_MAX_ATOM_TESTS_MANY);
+            direct = wgs <= DIRECT_MAX_WORKGROUPS && (long long)ncc * (long long)sp.per_molecule() * total <= limit;
         }
     }
 

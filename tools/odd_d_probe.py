@@ -62,6 +62,12 @@ if os.environ.get("ROUTE_SWEEP"):  # one molecule per call up to D = 64: is the 
             run(D, C)
             run(D, C, empty=True)
     sys.exit(0)
+if os.environ.get("SMALL_BATCH_SWEEP"):  # a few molecules per call: where the one-launch route should hand over (DIRECT unset / 0 / 1)
+    for D, C in ((64, 32), (64, 8), (48, 16), (32, 32)):
+        for B in (2, 3, 4, 6, 8, 16):
+            run(D, C)
+            run(D, C, empty=True)
+    sys.exit(0)
 if os.environ.get("PACE_SWEEP"):  # aligned sizes with 32-channel chunks, ~2 GB of grids per call: where the round pacing applies
     for D in (24, 32, 40, 48, 56, 64):
         B = max(8, (1 << 31) // (32 * D**3 * 4))
