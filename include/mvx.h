@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MVX_VERSION 130 /* 0.1.3: one voxelize launch per batched call (no second kernel), channel-wise radii grouped on the device; the ABI itself is unchanged since 0.1.2 (mvx_xform.center_ptr, stream hand-over, unaligned out, mvx_debug_set_option) */
+#define MVX_VERSION 140 /* 0.1.4: mvx_plan_call (the decision table as a pure function), the narrow-channel splat route; 0.1.3: one voxelize launch per batched call, channel-wise radii grouped on the device; 0.1.2: mvx_xform.center_ptr, stream hand-over, unaligned out, mvx_debug_set_option */
 
 typedef enum mvx_status {
     MVX_OK = 0,
@@ -218,6 +218,48 @@ int mvx_debug_read_records(mvx_handle *h, void *host_dst, int64_t n, void *strea
  *   "nw" = 1..16: waves (8-voxel z sub-tiles) per slab instead of the plan's (0 = the plan); measurement aid;
  *   "dense_grid": accepted and ignored (round 2's second voxelize launch no longer exists). */
 int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value);
+
+/*
+ * How a call of a given shape is executed: the library's whole decision table (route, slab decomposition, channel and
+ * molecule chunks, pacing, write-out path) as a pure host function - no handle, no device, nothing is launched. The forward
+ * entry points take exactly these decisions (with the handle's debug options applied on top). Exposed so that the table can
+ * be pinned by tests and read by callers who size their batches (the reference has no counterpart: it has one code path).
+ */
+enum mvx_route {
+    MVX_ROUTE_BINNED = 0,    /* prep -> xbin -> voxelize_kernel (slab lines; the batched float32 pipeline) */
+    MVX_ROUTE_DIRECT = 1,    /* voxelize_direct_kernel: the whole call in one launch (per-molecule calls) */
+    MVX_ROUTE_F64_DENSE = 2, /* float64 grids, general slab loop */
+    MVX_ROUTE_F64_MX = 3,    /* float64 grids, 32-channel chunks on the matrix cores */
+    MVX_ROUTE_SPLAT = 4      /* prep -> cbin -> voxelize_splat_kernel: narrow channel counts, atom-centric accumulation in LDS */
+};
+typedef struct mvx_plan_query {
+    int32_t dimension;
+    int32_t blockdim;      /* <= 0: the reference default 8 */
+    int32_t precision;     /* 32 (or 0) | 64 */
+    int32_t mode;          /* 0 features, 1 types, 2 single */
+    int32_t radii_type;    /* enum mvx_radii */
+    int32_t B, C;          /* molecules, channels */
+    int32_t out_aligned16; /* 1: the grid pointer is 16-byte aligned */
+    int64_t total_atoms;   /* over the batch */
+    int64_t max_atoms;     /* of one molecule */
+} mvx_plan_query;
+typedef struct mvx_plan {
+    int32_t route;            /* enum mvx_route */
+    int32_t nsx, nsy, nzc;    /* slabs along x, along y, z chunks of a row */
+    int32_t nw;               /* waves per slab: a slab is 2 x 4 x (8 nw) voxels (splat: 8 x 8 x (8 nw)) */
+    int32_t ct, ncc;          /* channels per workgroup, channel chunks */
+    int32_t nfull, ct_rem;    /* chunks of the main launch; width of the remainder launch's kernel (0: none) */
+    int32_t nchunk;           /* molecule chunks (gridDim.y limit, Infinity Cache budget, "chunks" option) */
+    int32_t pace;             /* 0 none, 1 empty slabs hold their zero fill back, 2 light slabs pace their rounds too */
+    int32_t grouped;          /* channel-wise radii for features: the grouped matrix-core launch */
+    int32_t lane_range;       /* sub-tiles straddle reference blocks: per-lane index ranges */
+    int32_t vec_store;        /* 16-byte stores (rows are whole 16-byte quads and the grid is aligned) */
+    int32_t xcd_ranges;       /* run-wise write-out with one contiguous slab range per XCD */
+    int32_t cpad;             /* channel weights per atom the voxelize kernels read */
+    int32_t weights_in_place; /* 1: the caller's feature rows are read in place (no packed copy) */
+    int32_t reserved;
+} mvx_plan;
+int mvx_plan_call(const mvx_plan_query *query, mvx_plan *plan);
 #ifdef __cplusplus
 }
 #endif

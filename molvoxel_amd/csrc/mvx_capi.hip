@@ -5,6 +5,7 @@
 // fully asynchronous on the caller's stream (no hidden device synchronisation). There is no CPU
 // fallback in this library: without a usable HIP device mvx_create fails.
 #include "mvx_internal.h"
+#include "mvx_plan.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -49,28 +50,6 @@ struct PinnedSlot {
 };
 
 constexpr int NSLOTS = 4;
-// voxelize_direct_kernel instead of the binned pipeline (run()): launches of at most this many workgroups (the
-// launch is latency-bound and every launch boundary saved counts; larger launches amortise the binning pre-pass, and
-// their many empty slabs are pure store streams in voxelize_kernel). Measured per call, binned / direct
-// (tools/route_rule.py): 512 workgroups 70 / 42 us (12 000 atoms), 1 024 workgroups 30 / 27 us, 2 304 workgroups
-// 30 / 44 us, 4 096 workgroups 31 / 63 us; 256 ligands in one call (131 072 workgroups) 0.64 / 2.04 ms ...
-constexpr double MALL_BUDGET = 288.0e6; // bytes of pre-pass data per voxelize launch (run(): chunking for the Infinity Cache)
-constexpr long long DIRECT_MAX_WORKGROUPS = 1536;
-#ifndef MVX_MX64_MIN_C
-#define MVX_MX64_MIN_C 16
-#endif
-constexpr int MX64_MIN_C = MVX_MX64_MIN_C; // float64 grids of more channels than this take the matrix-core slab kernel
-// ... and of at most this many atom tests (every workgroup scans its molecule's atoms: ~2 us per million)
-constexpr long long DIRECT_MAX_ATOM_TESTS = 16ll << 20;
-// ... with several channel chunks (C > 32) every chunk's workgroups scan, stage and walk again: one molecule per call, C = 64,
-// us per call one launch / binned: D = 64 4000 atoms 33 / 26, D = 48 1700 atoms 24 / 20 (0.97 M tests), D = 32 500 atoms
-// 13 / 18 (0.13 M), 8 atoms 10-18 / 17-20 - the one-launch route only up to this many tests then
-constexpr long long DIRECT_MAX_ATOM_TESTS_CHUNKED = 400000;
-// ... and launches of more than 512 workgroups (two or three molecules per call) only up to this many: the scans of the
-// second and third molecule's workgroups run on the same compute units as the first's - us per call one launch / binned,
-// cfg-2 density: D = 64 C = 32 two molecules 35 / 27, three 47 / 33; C = 8 28 / 21, 40 / 24; D = 48 C = 16 two 22 / 18, four
-// 34 / 21; 8-atom molecules stay (18 / 20, 24 / 27 at C = 32) (profiles/r03_odd_dimensions.txt)
-constexpr long long DIRECT_MAX_ATOM_TESTS_MANY = 300000;
 
 } // namespace
 
@@ -100,14 +79,11 @@ struct mvx_handle {
     std::vector<hipEvent_t> ev; // 2 * MVX_PROFILE_RING events, created on first use
     int ev_count = 0;           // timed launches recorded since the last read
     bool profiling = false;
-    int force_nw = 0;
-    int max_ct64 = 32; // channels per workgroup on float64 grids (debug option "max_ct64": 16 = two chunks for C = 32)
-    int max_ct = 32;
-    // Pipelined pre-pass (MVX_PIPELINE=k, k > 1): the batch is cut into k chunks of molecules; prep + binning of chunk
-    // j+1 run on a side stream while the caller's stream voxelizes chunk j. Off by default: on cfg-2 (64 molecules)
-    // the cross-stream waits and the extra launch boundaries cost more than the 50 us of pre-pass they hide
-    // (0.454 ms/step on one stream, 0.476 with 2 chunks, 0.513 with 4).
-    int pipeline = 1;
+    // test / measurement switches (mvx_debug_set_option): waves per slab, channels per workgroup, forced routes, molecule
+    // chunks with the pre-pass on a side stream ("chunks": off by default - on cfg-2 x 64 the cross-stream waits and the
+    // extra launch boundaries cost more than the 50 us of pre-pass they hide: 0.454 ms per step on one stream, 0.476 with 2
+    // chunks, 0.513 with 4), Infinity Cache budget
+    PlanKnobs knobs;
     // Stream hand-over: every call reuses the handle's workspace, ordered by the caller's stream. When a call arrives
     // on another stream than the previous one, the new stream first waits for everything the old stream holds
     // (event recorded on the old stream at that moment), so back-to-back calls on different streams never race.
@@ -117,12 +93,7 @@ struct mvx_handle {
     hipStream_t side = nullptr;
     hipEvent_t ev_in = nullptr;
     std::vector<hipEvent_t> ev_pre;
-    // -1: the library picks (run()); 0: always the binned three-launch pipeline; 1: always voxelize_direct_kernel
-    // (where it applies: float32 grids). Set by mvx_debug_set_option("direct", v) in tests and A/B runs.
-    double mall_budget = MALL_BUDGET; // bytes; mvx_debug_set_option("mall_budget_kb", v) lowers it in tests
-    int direct_mode = -1;
     int dbg = 0; // diagnostic builds (-DMVX_DIAG) only
-    int store_kind = 1; // nt: measured 0.69 -> 0.54 ms on cfg-2 (output lines do not displace the re-read inputs in L2)
 };
 
 namespace {
@@ -196,14 +167,6 @@ void make_geom(mvx_handle *h) {
     h->sigma32 = (float)c.sigma;
 }
 
-int pick_ct(int C) {
-    if (C <= 1) return 1;
-    if (C <= 4) return 4;
-    if (C <= 8) return 8;
-    if (C <= 16) return 16;
-    return 32;
-}
-
 struct RunArgs {
     int mode;
     const double *coords;
@@ -224,9 +187,17 @@ int adopt_stream(mvx_handle *h, hipStream_t s) {
     if (h->used && h->last_stream != s) {
         if (!h->ev_switch) HIP_TRY(hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming));
         // (the previous stream is alive by contract - mvx.h: "a stream must stay alive until the next call on the handle
-        // has returned"; a destroyed handle cannot be detected reliably, so nothing here pretends to)
-        HIP_TRY(hipEventRecord(h->ev_switch, h->last_stream));
-        HIP_TRY(hipStreamWaitEvent(s, h->ev_switch, 0));
+        // has returned". If recording on it fails all the same, the error is reported once, the sticky HIP error is
+        // cleared and the handle moves on to the new stream behind a device-wide synchronisation: one caller mistake
+        // must not wedge the handle for good.)
+        hipError_t e = hipEventRecord(h->ev_switch, h->last_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, h->ev_switch, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();
+            h->last_stream = s;
+            return fail_hip(e, "stream hand-over (was the previous call's stream destroyed?)");
+        }
     }
     h->last_stream = s;
     h->used = true;
@@ -346,40 +317,7 @@ int stage_inputs(mvx_handle *h, Workspace &w, const RunArgs &r, int64_t total, s
     return MVX_OK;
 }
 
-// ---- 3. slab decomposition of the grid ------------------------------------------------------------------------------
-// slab = SUBX x SUBY x (SUBZ*NW) voxels, NW waves side by side along z. Whole rows (NW = row length in sub-tiles) up to
-// 8 waves; longer rows are cut into chunks of 8 sub-tiles (256-B runs).
-// whole_rows (the binned float32 pipeline): rows of 65 ... 128 voxels stay whole too (9 ... 16 waves, the 1024-thread
-// kernel variants, two or three workgroups per compute unit) unless D % 32 == 0. A row cut at 256 B leaves pieces that
-// share 64-byte blocks with their neighbours whenever rows are not multiples of 64 B - 16 molecules per call, C = 32,
-// TB/s of grid bytes, chunks -> whole rows: D = 72 1.80 -> 4.16, 88 1.94 -> 4.02, 104 2.12 -> 4.03, 120 2.25 -> 3.81,
-// 80 3.70 -> 4.12, 112 3.95 -> 4.02, 65 2.13 -> 2.57; D = 96 4.26 -> 4.28 and D = 128 5.13 -> 4.22 keep their chunks
-// (tools/odd_d_probe.py ROW_SWEEP=1, profiles/r03_odd_dimensions.txt).
-struct SlabPlan {
-    int nsx, nsy, nzc, NW;
-    size_t per_molecule() const { return (size_t)nsx * nsy * nzc; }
-};
-
-SlabPlan plan_slabs(const mvx_handle *h, int max_waves, bool whole_rows = false) {
-    const int D = h->g.D;
-    SlabPlan sp;
-    sp.nsx = (D + SUBX - 1) / SUBX;
-    sp.nsy = (D + SUBY - 1) / SUBY;
-    const int nsz = (D + SUBZ - 1) / SUBZ;
-    sp.NW = nsz <= max_waves ? nsz : max_waves;
-    if (whole_rows && nsz > max_waves && nsz <= 16 && D % 32 != 0) sp.NW = nsz;
-    // longer rows that are not multiples of 64 B: as few, equally long chunks as 16 waves allow (every cut shares a 64-byte
-    // block between two workgroups) - D = 136 1.90 -> 2.10 TB/s, 152 2.28 -> 2.50, 168 2.01 -> 2.19, 200 (C = 16) 1.68 ->
-    // 1.89; multiples of 64 B keep chunks of 8 (D = 144 3.36 against 2.54-2.67, 160 3.60 against 2.81-3.15)
-    if (whole_rows && nsz > 16 && D % 16 != 0) {
-        const int k = (nsz + 15) / 16;
-        sp.NW = (nsz + k - 1) / k;
-    }
-    if (h->force_nw > 0 && h->force_nw <= 16) sp.NW = std::min(h->force_nw, nsz); // MVX_NW experiment knob
-    sp.nzc = (nsz + sp.NW - 1) / sp.NW;
-    return sp;
-}
-
+// ---- 3. how the call is executed: plan_call (mvx_plan.hip) ---------------------------------------------------------
 inline uint32_t umulhi_inverse(int d) { // n / d == __umulhi(n, inv) for the slab ids used (n * d < 2^32); d == 1 is special-cased by the kernel
     return d == 1 ? 0xffffffffu : (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d);
 }
@@ -416,65 +354,31 @@ int run(mvx_handle *h, const RunArgs &r) {
     const bool f64 = (h->cfg.precision == 64);
     const size_t esz = f64 ? sizeof(double) : sizeof(float); // element size of features, radii and the grid
     const size_t out_bytes = (size_t)r.B * r.C * D * D * D * esz;
-
-    // channels per workgroup (register accumulators per lane); more channels -> several channel chunks
-    // float64 grids: 16 channels per workgroup (two chunks for C = 32: 105 VGPRs, two 8-wave workgroups per compute
-    // unit). Gaussian grids of more than 16 channels take 32 per workgroup on 4-wave slabs instead (147 VGPRs, three
-    // workgroups per unit): distances and exp are evaluated once per slab instead of once per chunk, 3.4 -> 3.7 TB/s on
-    // cfg-2; the binary kernel has no exp to save and is faster as it was (4.1 against 3.5 TB/s). Measured and not used:
-    // 32 channels on 8-wave slabs (one workgroup per unit: 3.05 / 2.7 TB/s), 16 channels squeezed into 80 VGPRs for
-    // three 8-wave workgroups (26 dwords of scratch in the walk: 2.5 TB/s).
-    // Round 3: more than 16 channels with scalar / atom-wise radii take chunks of 32 on 8-wave slabs through the
-    // matrix-core slab kernel (voxelize64_kernel, 128 registers, two workgroups per unit): a.p.dcap == 0 selects it.
-    const bool mx64 = f64 && r.C > MX64_MIN_C && !(r.radii_type == MVX_RADII_CHANNEL && r.mode == MODE_FEATURES) && h->max_ct64 >= 32 &&
-                      h->max_ct >= 32 && h->force_nw == 0;
-    SlabPlan sp = plan_slabs(h, 8);
-    const int ct = mx64 ? 32 : pick_ct(std::min(r.C, f64 ? std::min(h->max_ct, 16) : h->max_ct));
-    const int ncc = (r.C + ct - 1) / ct;
-    // One launch for the whole call (voxelize_direct_kernel) when the per-workgroup atom scan is cheap next to the
-    // slab's stores: per-molecule forward() calls, and batches of small molecules. Bigger jobs amortise the binning
-    // pre-pass and take the three-launch pipeline.
-    bool direct = false;
-    // (whole-row slabs only, D <= 64: with rows cut in two the one-launch route loses to the binned pipeline at every size
-    // measured - one molecule per call, D = 68 / 72 / 76, us per call one launch / binned: 4000-atom-density pocket 57 / 23,
-    // 65 / 24, 69 / 27; 8 atoms 24 / 18, 26 / 19, 28 / 23; C = 8 48 / 20, 54 / 19, 58 / 22 - profiles/r03_odd_dimensions.txt)
-    if (!f64 && sp.NW <= 8 && sp.nzc == 1 && (long long)r.B * ncc <= 65535) {
-        if (h->direct_mode >= 0) direct = h->direct_mode == 1;
-        else {
-            const long long wgs = (long long)r.B * ncc * (long long)sp.per_molecule();
-            const long long limit = ncc > 1 ? DIRECT_MAX_ATOM_TESTS_CHUNKED : (wgs <= 512 ? DIRECT_MAX_ATOM_TESTS : DIRECT_MAX_ATOM_TESTS_MANY);
-            direct = wgs <= DIRECT_MAX_WORKGROUPS && (long long)ncc * (long long)sp.per_molecule() * total <= limit;
-        }
+    void *d_out = r.out;
+    if (r.out_kind == MVX_HOST) {
+        if ((rc = ensure(h->out_stage, out_bytes))) return rc;
+        d_out = h->out_stage.p;
     }
 
-    if (!f64 && !direct) sp = plan_slabs(h, 8, true);
+    // ---- how this call is executed: one pure function of its shape (mvx_plan.hip, pinned by tests/test_plan.py) --------
+    mvx_plan_query q{};
+    q.dimension = D;
+    q.blockdim = g.bd;
+    q.precision = f64 ? 64 : 32;
+    q.mode = r.mode;
+    q.radii_type = r.radii_type;
+    q.B = r.B;
+    q.C = r.C;
+    q.out_aligned16 = (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0 ? 1 : 0;
+    q.total_atoms = total;
+    q.max_atoms = max_atoms;
+    const mvx_plan plan = plan_call(q, h->knobs);
+    const bool direct = plan.route == MVX_ROUTE_DIRECT;
+    const bool mx64 = plan.route == MVX_ROUTE_F64_MX;
+    const int ct = plan.ct, ncc = plan.ncc, nchunk = plan.nchunk;
+    const size_t per_molecule = (size_t)plan.nsx * plan.nsy * plan.nzc;
 
-    // Channel counts that are not a multiple of the chunk width (C = 33 ... 63, 65 ...): the binned float32 pipeline runs
-    // the full chunks with the wide kernel and the remainder with the narrowest kernel that holds it (C = 33: 32 + 1,
-    // C = 40: 32 + 8) - a second, small voxelize launch over the same candidate lines - instead of a whole extra chunk of
-    // `ct` accumulators that are mostly padding (C = 33 cost +49 % for +3 % of the bytes).
-    int nfull = ncc, ct_rem = 0;
-    if (!f64 && !direct && ncc > 1 && r.C % ct != 0) {
-        ct_rem = pick_ct(r.C - (r.C / ct) * ct);
-        if (ct_rem < ct) nfull = r.C / ct;
-        else ct_rem = 0; // (a remainder of more than half a chunk needs the wide kernel anyway: one launch, as before)
-    }
-
-    // ---- molecules in chunks (gridDim.y limit; optionally pre-pass on the side stream, one chunk ahead) ----------
-    const int max_mol = 65535 / ncc;
-    int nchunk = (r.B + max_mol - 1) / max_mol;
-    // A chunk's pre-pass output and inputs (records, binning keys, feature rows, slab lines) are re-read ~20 times by its
-    // voxelize launch; while they fit the 256 MiB Infinity Cache the row loads are served on-die. One launch over 512
-    // cfg-2 molecules (526 MB of them) ran at 0.65 of peak against 0.76 for 256: larger batches are cut so that each
-    // chunk's set stays under MALL_BUDGET, and pre-pass and voxelize launches alternate chunk by chunk.
-    {
-        const double per_atom = 64.0 + 8.0 + 4.0 * (double)((r.C + 3) / 4 * 4) * (f64 ? 2.0 : 1.0);
-        const double ws = (double)total * per_atom + (double)r.B * (double)sp.per_molecule() * 512.0;
-        const int mall_chunks = (int)std::min<double>(std::ceil(ws / h->mall_budget), (double)std::max(1, r.B));
-        if (!f64 && mall_chunks > nchunk) nchunk = mall_chunks;
-    }
-    const bool forced_pipeline = h->pipeline > 1 && r.B >= 4 * h->pipeline;
-    if (forced_pipeline) nchunk = std::max(nchunk, h->pipeline);
+    const bool forced_pipeline = h->knobs.pipeline > 1 && r.B >= 4 * h->knobs.pipeline;
     // Cross-call overlap (mvx_set_overlap): this call's pre-pass fills the other workspace set on the side stream,
     // under the previous call's voxelize launches. Device-resident inputs and outputs only.
     // Batches only (mvx.h: "the batched three-launch path"): a per-molecule call hands over arrays its Python layer may
@@ -518,26 +422,19 @@ int run(mvx_handle *h, const RunArgs &r) {
     } else if ((rc = stage_inputs(h, w, r, total, esz, overlap ? pre : s, in))) {
         return rc;
     }
-    void *d_out = r.out;
-    if (r.out_kind == MVX_HOST) {
-        if ((rc = ensure(h->out_stage, out_bytes))) return rc;
-        d_out = h->out_stage.p;
-    }
 
     // ---- workspace --------------------------------------------------------------------------------
     const size_t n_alloc = (size_t)std::max<int64_t>(total, 1);
-    // channel weights per atom, zero padded
-    const int Cpad = ct_rem ? nfull * ct + (ct_rem < 4 ? 4 : ct_rem) : ((ncc > 1) ? ncc * ct : (ct < 4 ? 4 : ct));
-    // feature rows that already are Cpad wide are read in place; anything else (one-hot types, 1, padding) is packed
-    const bool direct_w = (r.mode == MODE_FEATURES && r.C == Cpad);
-    const size_t nslabs = (size_t)r.B * sp.per_molecule();
+    const int Cpad = plan.cpad;
+    const bool direct_w = plan.weights_in_place != 0;
+    const size_t nslabs = (size_t)r.B * per_molecule;
     if (nslabs * (size_t)ncc + 1 > (size_t)0x7fffffff) return fail(MVX_ERR_INVALID, "batch too large for one call");
     if (!direct) {
         if ((rc = ensure(w.rec, n_alloc * sizeof(AtomRec)))) return rc;
         if (!direct_w && (rc = ensure(w.wbuf, n_alloc * (size_t)Cpad * esz))) return rc;
         if ((rc = ensure(w.xp, n_alloc * sizeof(uint2)))) return rc;
         // x-lists: packed regions, (sum(N) + 2*B) * nsx entries; slab lines: primary + extension entries per slab
-        if ((rc = ensure(w.xlist, ((size_t)total + 2 * (size_t)r.B) * sp.nsx * sizeof(uint2)))) return rc;
+        if ((rc = ensure(w.xlist, ((size_t)total + 2 * (size_t)r.B) * plan.nsx * sizeof(uint2)))) return rc;
         if ((rc = ensure(w.slist, nslabs * (SLAB_LINE_ENTRIES + SLAB_EXT_ENTRIES) * sizeof(uint2)))) return rc;
     }
     uint2 *d_xlist = reinterpret_cast<uint2 *>(w.xlist.p);
@@ -551,23 +448,24 @@ int run(mvx_handle *h, const RunArgs &r) {
     float *d_kc = nullptr;
     ChanGroups *d_groups = nullptr;
     int32_t *d_chan_slot = nullptr;
-    if (chanwise && !direct) {
-        // [max radius | ChanGroups | per-channel thresholds | per-channel coefficients] (the per-channel kernel finds the
-        // table right below its thresholds)
-        const size_t tc_off = 16 + align_up(sizeof(ChanGroups), 16), kc_off = tc_off + align_up((size_t)r.C * sizeof(double), 16);
-        const size_t slot_off = kc_off + align_up((size_t)r.C * sizeof(double), 16); // the channels' radius slots (int32 x C)
-        if ((rc = ensure(w.aux, slot_off + (size_t)r.C * sizeof(int32_t)))) return rc; // (float64 handles: double coefficients)
-        d_chan_slot = reinterpret_cast<int32_t *>((char *)w.aux.p + slot_off);
-        d_rmax = w.aux.p;
-        d_groups = reinterpret_cast<ChanGroups *>((char *)w.aux.p + 16);
-        d_Tc = reinterpret_cast<double *>((char *)w.aux.p + tc_off);
-        d_kc = reinterpret_cast<float *>((char *)w.aux.p + kc_off);
-        if (f64)
+    if (chanwise) {
+        if (f64) { // [max radius | per-channel thresholds | per-channel coefficients]
+            const size_t tc_off = 16, kc_off = tc_off + align_up((size_t)r.C * sizeof(double), 16);
+            if ((rc = ensure(w.aux, kc_off + (size_t)r.C * sizeof(double)))) return rc;
+            d_rmax = w.aux.p;
+            d_Tc = reinterpret_cast<double *>((char *)w.aux.p + tc_off);
+            d_kc = reinterpret_cast<float *>((char *)w.aux.p + kc_off); // (double coefficients behind a float pointer)
             HIP_TRY(launch_chan_aux64(static_cast<const double *>(in.radii), r.C, h->cfg.density, h->cfg.sigma,
                                       static_cast<double *>(d_rmax), d_Tc, reinterpret_cast<double *>(d_kc), overlap ? pre : s));
-        else
-            HIP_TRY(launch_chan_aux(static_cast<const float *>(in.radii), r.C, h->cfg.density, h->sigma32,
-                                    static_cast<float *>(d_rmax), d_Tc, d_kc, d_groups, d_chan_slot, overlap ? pre : s));
+        } else { // [max radius | one ChanGroups per chunk of 32 channels | the channels' radius slots (int32 x C)]
+            const size_t slot_off = 16 + (size_t)ncc * sizeof(ChanGroups);
+            if ((rc = ensure(w.aux, slot_off + (size_t)r.C * sizeof(int32_t)))) return rc;
+            d_rmax = w.aux.p;
+            d_groups = reinterpret_cast<ChanGroups *>((char *)w.aux.p + 16);
+            d_chan_slot = reinterpret_cast<int32_t *>((char *)w.aux.p + slot_off);
+            HIP_TRY(launch_chan_aux(static_cast<const float *>(in.radii), r.C, h->cfg.density, h->sigma32, static_cast<float *>(d_rmax),
+                                    d_groups, d_chan_slot, overlap ? pre : s));
+        }
     }
 
     // ---- kernel arguments -------------------------------------------------------------------------
@@ -620,41 +518,30 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.D = D;
     va.p.C = r.C;
     va.p.B = r.B;
-    va.p.nsx = sp.nsx;
-    va.p.nsy = sp.nsy;
-    va.p.nzc = sp.nzc;
+    va.p.nsx = plan.nsx;
+    va.p.nsy = plan.nsy;
+    va.p.nzc = plan.nzc;
     va.p.ncc = ncc;
-    va.p.nsy_inv = umulhi_inverse(sp.nsy);
-    va.p.nzc_inv = umulhi_inverse(sp.nzc);
+    va.p.nsy_inv = umulhi_inverse(plan.nsy);
+    va.p.nzc_inv = umulhi_inverse(plan.nzc);
     va.p.b0 = 0;
     va.p.c0 = 0;
-    va.p.NW = sp.NW;
-    va.p.w_stride = Cpad;
-    va.p.dcap = f64 ? (mx64 ? 0 : 64) : voxelize_dcap(ct, sp.NW);
-    // 16-B stores need whole float4 groups per row (D % 4 == 0) and a 16-B aligned grid; anything else (odd
-    // dimensions, a slice `grid[i]` of a batch grid whose slices are not 16-B multiples) takes the scalar-store path
-    va.p.vec_store = (D % (f64 ? 2 : 4) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) ? 1 : 0;
-    va.p.xcd_ranges = (!f64 && !va.p.vec_store && sp.nzc == 1) ? 1 : 0;
-    va.p.store_kind = h->store_kind;
-    // 1: empty slabs hold their zero fill back and send it in pieces (launches of more than 4096 workgroups); 2: light slabs
-    // also pace their write-out rounds (OpsMx32::write) - launches of at least 49 152 workgroups (96 cfg-2 molecules): same
-    // box, cfg-2 kernel of peak in sustained back-to-back calls, unpaced -> paced rounds: 16 molecules 0.734 -> 0.715, 32:
-    // 0.767 -> 0.745, 64: 0.773 -> 0.785, 128: 0.775 -> 0.801, 256: 0.768 -> 0.801; in short bursts on a cool GPU (25 calls)
-    // 64 molecules lose 3-5 % instead, hence the limit above them (profiles/r03_round_pacing.txt)
-    const size_t wgs = nslabs * (size_t)ncc;
-    va.p.pace = wgs >= 49152 ? 2 : (wgs > 4096 ? 1 : 0);
+    va.p.NW = plan.nw;
+    va.p.w_stride = plan.grouped ? r.C : Cpad;
+    va.p.dcap = f64 ? (mx64 ? 0 : 64) : 0; // (float64: rows per round of the general slab loop, 0 selects the matrix-core kernel)
+    va.p.vec_store = plan.vec_store;
+    va.p.xcd_ranges = plan.xcd_ranges;
+    va.p.pace = plan.pace;
     va.p.sigma = h->cfg.sigma;
 #ifdef MVX_DIAG
     va.p.dbg = h->dbg;
 #endif
-    // a sub-tile lies inside one reference block when its edges divide blockdim (or there is a single block):
-    // the block cull is then wave-uniform and already folded into the candidate ranges.
-    const bool lr_blocks = !(g.nb == 1 || (g.bd % SUBX == 0 && g.bd % SUBY == 0 && g.bd % SUBZ == 0));
     // float32 grids whose rows are not whole 16-byte quads need the run-wise write-out (store_runs): compiled into the
     // per-lane-range kernels and into voxelize_runs_kernel (the matrix-core walk of 32-channel chunks), nowhere else
+    const bool lr_blocks = plan.lane_range != 0;
     const bool runs = !f64 && !va.p.vec_store;
     const bool lane_range = lr_blocks || runs;
-    auto lane_range_for = [&](int32_t ct_) { return lr_blocks || (runs && !(ct_ == 32 && !chanwise)); };
+    auto lane_range_for = [&](int32_t ct_) { return lr_blocks || (runs && ct_ != 32); };
 
     if (direct) {
         DirectArgs da;
@@ -677,9 +564,7 @@ int run(mvx_handle *h, const RunArgs &r) {
                 if (r.in_kind == MVX_HOST) resolve_host_centers(&da.pa.xf_one, 1);
             }
         }
-        if ((rc = timed_launch(h, s, [&] {
-                 return launch_voxelize_direct(da, va.p, static_cast<float *>(d_out), ct, gauss, chanwise, lane_range, s);
-             })))
+        if ((rc = timed_launch(h, s, [&] { return launch_voxelize_direct(da, va.p, static_cast<float *>(d_out), ct, gauss, lane_range, s); })))
             return rc;
         if (in.slot) {
             HIP_TRY(hipEventRecord(in.slot->done, s));
@@ -709,7 +594,7 @@ int run(mvx_handle *h, const RunArgs &r) {
         pa.first = r.offsets[b0];
         pa.total = r.offsets[b1];
         HIP_TRY(launch_prep(pa, pre));
-        HIP_TRY(launch_xbin(pa.xp, in.offsets, total, b0, b1 - b0, max_atoms, sp.nsx, sp.nsy, sp.nzc, sp.NW, d_xlist, d_slist,
+        HIP_TRY(launch_xbin(pa.xp, in.offsets, total, b0, b1 - b0, max_atoms, plan.nsx, plan.nsy, plan.nzc, plan.nw, d_xlist, d_slist,
                             d_slist_ext, pre));
         if (side_stream) HIP_TRY(hipEventRecord(overlap ? w.ev_pre : h->ev_pre[k], pre));
         return MVX_OK;
@@ -717,7 +602,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     const bool interleave = !side_stream && !f64 && nchunk > 1; // chunk by chunk: pre-pass, then its voxelize launch
     for (int k = 0; k < nchunk && !interleave; ++k)
         if ((rc = prepass(k))) return rc;
-    if (f64) { // float64 grids: one launch of the general slab loop over the whole batch
+    if (f64) { // float64 grids: one launch over the whole batch
         for (int k = 0; k < nchunk && side_stream; ++k) HIP_TRY(hipStreamWaitEvent(s, overlap ? w.ev_pre : h->ev_pre[k], 0));
         if ((rc = timed_launch(h, s, [&] { return launch_voxelize64(va, ct, gauss, chanwise, lr_blocks, s); }))) return rc;
     } else {
@@ -726,31 +611,23 @@ int run(mvx_handle *h, const RunArgs &r) {
             if (interleave && (rc = prepass(k))) return rc;
             if (side_stream) HIP_TRY(hipStreamWaitEvent(s, overlap ? w.ev_pre : h->ev_pre[k], 0));
             va.p.b0 = b0;
-            if (chanwise) {
+            if (plan.grouped) {
                 // channels grouped by radius (chan_aux_kernel): chunks of 32 channels on the matrix-core path, one
-                // threshold test and one density per radius slot and candidate, feature rows read in place. The
-                // per-channel launch below returns at once unless there were more distinct radii than slots.
+                // threshold test and one density per radius slot and candidate, feature rows read in place
                 VoxArgs vg = va;
-                vg.w = reinterpret_cast<const unsigned *>(in.channels);
-                vg.p.w_stride = r.C;
-                vg.p.ncc = (r.C + 31) / 32;
-                vg.p.c0 = 0;
                 vg.Tc = reinterpret_cast<const double *>(d_groups);
                 vg.kc = reinterpret_cast<const float *>(d_chan_slot);
-                const int per = 65535 / vg.p.ncc;
-                for (int m0 = b0; m0 < b1; m0 += per) {
-                    vg.p.b0 = m0;
-                    if ((rc = timed_launch(h, s, [&] { return launch_voxelize_grouped(vg, std::min(per, b1 - m0), gauss, lane_range, s); }))) return rc;
-                }
+                if ((rc = timed_launch(h, s, [&] { return launch_voxelize_grouped(vg, b1 - b0, gauss, lane_range, s); }))) return rc;
+                continue;
             }
-            va.p.ncc = nfull;
+            va.p.ncc = plan.nfull;
             va.p.c0 = 0;
             // the bracket holds voxelize_kernel alone (what rocprofv3 reports under that name)
-            if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, ct, gauss, chanwise, lane_range_for(ct), s); }))) return rc;
-            if (ct_rem) { // the remainder channels [nfull * ct, C) with a narrower kernel
+            if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, ct, gauss, lane_range_for(ct), s); }))) return rc;
+            if (plan.ct_rem) { // the remainder channels [nfull * ct, C) with a narrower kernel
                 va.p.ncc = 1;
-                va.p.c0 = nfull * ct;
-                if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, ct_rem, gauss, chanwise, lane_range_for(ct_rem), s); }))) return rc;
+                va.p.c0 = plan.nfull * ct;
+                if ((rc = timed_launch(h, s, [&] { return launch_voxelize(va, b1 - b0, plan.ct_rem, gauss, lane_range_for(plan.ct_rem), s); }))) return rc;
             }
         }
     }
@@ -818,12 +695,6 @@ int mvx_create(const mvx_config *cfg, mvx_handle **out) {
     h->cfg = *cfg;
     h->device = cfg->device;
     make_geom(h);
-#ifdef MVX_EXPERIMENT // A/B builds only (make EXPERIMENT=1): the shipped library reads no environment variable
-    if (const char *env = std::getenv("MVX_NW")) h->force_nw = std::atoi(env);
-    if (const char *env = std::getenv("MVX_STORE")) h->store_kind = std::atoi(env);
-    if (const char *env = std::getenv("MVX_CT")) h->max_ct = std::max(1, std::min(32, std::atoi(env)));
-    if (const char *env = std::getenv("MVX_PIPELINE")) h->pipeline = std::max(1, std::min(16, std::atoi(env)));
-#endif
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) {
         delete h;
@@ -1018,13 +889,15 @@ int mvx_debug_read_records(mvx_handle *h, void *host_dst, int64_t n, void *strea
 int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
     if (!h || !name) return fail(MVX_ERR_INVALID, "null argument");
     const std::string n(name);
-    if (n == "chunks") h->pipeline = std::max(1, std::min(16, (int)value));
-    else if (n == "max_ct") h->max_ct = std::max(1, std::min(32, (int)value));
-    else if (n == "direct") h->direct_mode = value < 0 ? -1 : (value ? 1 : 0);
-    else if (n == "max_ct64") h->max_ct64 = value >= 32 ? 32 : 16;
+    PlanKnobs &k = h->knobs;
+    if (n == "chunks") k.pipeline = std::max(1, std::min(16, (int)value));
+    else if (n == "max_ct") k.max_ct = std::max(1, std::min(32, (int)value));
+    else if (n == "direct") k.direct_mode = value < 0 ? -1 : (value ? 1 : 0);
+    else if (n == "splat") k.splat_mode = value < 0 ? -1 : (value ? 1 : 0);
+    else if (n == "max_ct64") k.max_ct64 = value >= 32 ? 32 : 16;
     else if (n == "dense_grid") (void)value; // (accepted and ignored: there is no second voxelize launch any more)
-    else if (n == "nw") h->force_nw = (value >= 1 && value <= 16) ? value : 0; // waves (8-voxel z sub-tiles) per slab; 0 = the default plan
-    else if (n == "mall_budget_kb") h->mall_budget = value > 0 ? 1024.0 * (double)value : MALL_BUDGET;
+    else if (n == "nw") k.force_nw = (value >= 1 && value <= 16) ? value : 0; // waves (8-voxel z sub-tiles) per slab; 0 = the default plan
+    else if (n == "mall_budget_kb") k.mall_budget = value > 0 ? 1024.0 * (double)value : MALL_BUDGET;
 #ifdef MVX_DIAG
     else if (n == "dbg") h->dbg = value;
     else if (n == "vk_stamps") { // value = workgroups to make room for (0: off); read back with mvx_debug_read_diag

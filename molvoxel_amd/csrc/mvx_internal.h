@@ -86,7 +86,6 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
     int32_t w_stride;      // floats between the channel weights of consecutive atoms
     int32_t dcap;          // candidate rows staged per round
     int32_t vec_store;     // D % 4 == 0 and out 16-B aligned
-    int32_t store_kind;    // 0 plain, 1 nt, 2 sc1 (MVX_STORE)
     int32_t pace;          // 1: empty slabs hold their stores back ~1.7 us (launches of more than 4096 workgroups); 2: light slabs pace their write-out rounds too (>= 49 152)
     int32_t xcd_ranges;    // 1: every XCD takes a contiguous range of slabs (run-wise write-out of whole-row slabs; gridDim.x = 8 ceil(T / 8))
     double sigma;          // float64 grids: the Gaussian sigma as the reference holds it (python float)
@@ -104,14 +103,13 @@ struct DirectArgs {
 };
 
 // Channel-wise radii for features (numpy/voxelizer.py:213-224: one membership test and one density per channel): channels
-// that share a radius share both. chan_aux_kernel numbers the distinct radii (slots, in order of first appearance) and
-// the grouped voxelize launch evaluates, per candidate pair, one threshold test and one exp2 per SLOT and feeds the
-// matrix cores the weight row masked to that slot's channels - d2, staging, culls and the stores are shared by all slots.
-// More than CHAN_GROUP_SLOTS distinct radii: `fallback` = 1, the grouped launch returns at once and the general
-// per-channel kernel (which returns at once otherwise) does the call.
-constexpr int CHAN_GROUP_SLOTS = 32; // (one bit each in the chunk's slot mask)
+// that share a radius share both. chan_aux_kernel numbers the distinct radii of every chunk of 32 channels (slots, by
+// descending radius; one ChanGroups per chunk) and the grouped voxelize launch evaluates, per candidate pair, one threshold
+// test and one exp2 per SLOT and feeds the matrix cores the weight row masked to that slot's channels - d2, staging, culls
+// and the stores are shared by all slots. 32 channels have at most 32 distinct radii: there is no fallback kernel.
+constexpr int CHAN_GROUP_SLOTS = 32;
 struct ChanGroups {
-    int32_t nslots, fallback, pad[2];
+    int32_t nslots, pad[3];
     struct {
         double T;  // d2_threshold(radius)
         float k;   // gauss_coeff(radius, sigma)
@@ -133,29 +131,29 @@ struct VoxArgs {
     VoxParams p;
 };
 
-// launchers (host side, mvx_kernels.hip)
+// launchers (host side: mvx_prep.hip, mvx_slab.hip, mvx_direct.hip, mvx_f64.hip)
 // chan_slot: C ints, the slot of every channel (grouped launch)
-hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax,
-                           double *Tc, float *kc, ChanGroups *groups, int32_t *chan_slot, hipStream_t s);
+hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax, ChanGroups *groups,
+                           int32_t *chan_slot, hipStream_t s);
 hipError_t launch_chan_aux64(const double *radii, int32_t C, int32_t density, double sigma, double *rmax, double *Tc, double *kc,
                              hipStream_t s);
 hipError_t launch_prep(const PrepArgs &a, hipStream_t s);
 hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, int32_t b0, int32_t nb, int64_t max_atoms, int32_t nsx, int32_t nsy,
                        int32_t nzc, int32_t NW, uint2 *xlist, uint2 *slist, uint2 *slist_ext, hipStream_t s);
-constexpr int SLAB_LINE_ENTRIES = 64;  // = SLOTS in mvx_kernels.hip
+constexpr int SLAB_LINE_ENTRIES = 64;  // = SLOTS in mvx_device.h
 constexpr int SLAB_EXT_ENTRIES = 192;  // = EXT_SLOTS
 hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf_dev, double *out, hipStream_t s);
 // ct: channels per thread (1, 4, 8, 16, 32); lane_range: per-lane index-range check needed
 // voxelize molecules [a.p.b0, a.p.b0 + nb): every slab, whatever its candidate count (line, line + extension, x-list)
-hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
-// channel-wise features, grouped by radius: a.Tc must point at the ChanGroups table, a.kc at the channels' slots;
+hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss, bool lane_range, hipStream_t s);
+// channel-wise features, grouped by radius: a.Tc must point at the chunks' ChanGroups tables, a.kc at the channels' slots;
 // chunks of 32 channels (a.p.ncc = ceil(C / 32)), feature rows read in place
 hipError_t launch_voxelize_grouped(const VoxArgs &a, int32_t nb, bool gauss, bool lane_range, hipStream_t s);
 // float64 grids: every slab of the whole batch through the general slab loop (ct <= 16; a.p.dcap must be 64)
 hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
 // the whole call in one launch (float32 grids, NW <= 8): no workspace, no pre-pass
-hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, bool chanwise,
-                                  bool lane_range, hipStream_t s);
+hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, bool lane_range,
+                                  hipStream_t s);
 void scalar_radius_constants(double radius_scalar, float sigma32, bool gauss, double *T, float *k);
 // profiled launches: the next voxelize launch on this thread carries these events on its own dispatch packet
 void set_launch_events(hipEvent_t start, hipEvent_t stop);

@@ -1,0 +1,62 @@
+// mvx_tuning.h - every measured constant of the kernels and of the host-side plan, in one place, each with the measurement
+// that chose it (MI355X, same-box A/B runs; the tables are in profiles/, the history in profiles/HISTORY.md).
+#pragma once
+
+namespace mvx {
+
+// ---- write-out rounds (channels transposed through LDS per round) --------------------------------------------------------
+// vector-ALU slab kernels: 512 threads read back exactly one 32-row tile per round. cfg-2 x 256, of peak: 16 channels per
+// round 0.783-0.787, 8: 0.790, 4: 0.792-0.795 - smaller store bursts interleave better between a unit's workgroups.
+constexpr int CR_F32 = 4;
+constexpr int MX_CR = 8;      // matrix-core path: D holds 4 channels x 2 planes per lane and round
+constexpr int DIRECT_CR = 16; // per-molecule launches: 512 workgroups store once, fewer barriers win (cfg-2 call 21.2 -> 20.4 us)
+constexpr int CR64 = 8;       // float64 grids
+
+// ---- pacing of the store stream (profiles/r03_round_pacing.txt) -----------------------------------------------------------
+// s_sleep counts units of 64 cycles. An empty slab holds its zero fill back EMPTY_HOLD units (ligand batches 6.2 -> 6.7 TB/s;
+// 16 / 32 / 48 / 64 / 80 / 100 units: +0.9 / 2.8 / 4.7 / 7.5 / 7.0 / 3.7 %) and sends it in pieces of two store instructions
+// EMPTY_SPLIT units apart (6.55 -> 6.83 TB/s; 8 / 16 / 24 / 32 units: +2 / +3.5 / +4.3 / +3.6 %).
+constexpr int EMPTY_HOLD = 64;
+constexpr int EMPTY_SPLIT = 20;
+// A light slab of a store-bound launch waits after each write-out round about as long as a compute unit needs to drain the
+// round's bytes: 8 channels x 64 NW voxels x 4 B at ~12.8 B per cycle = 2.5 NW units (NW = 8: 20 units = 1280 cycles; cfg-2 x
+// 256 of peak, 4 / 16 / 20 / 24 / 30 / 40 units: +0.5 / +2.3 / +2.5...4.7 / +2 / +0.5 / -7 %). Issued as NW/2 sleeps of
+// ROUND_SLEEP_STEP units (s_sleep takes an immediate).
+constexpr int ROUND_SLEEP_STEP = 5;
+// ... only slabs of at most this many candidates: heavier slabs are bound by their walk and lose by waiting (1.5 A radius:
+// -5 % with every slab paced, +1 % with the limit; 2.0 A: +2 %)
+constexpr int PACE_MAX_CANDIDATES = 48;
+// ... and only in launches of at least PACE_ROUNDS_MIN_WGS workgroups (96 cfg-2 molecules; unpaced -> paced, of peak: 16
+// molecules 0.734 -> 0.715, 32: 0.767 -> 0.745, 64: 0.773 -> 0.785, 128: 0.775 -> 0.801, 256: 0.768 -> 0.801); empty slabs
+// are held back in launches of more than PACE_EMPTY_MIN_WGS workgroups (a small launch would just start later)
+constexpr long long PACE_ROUNDS_MIN_WGS = 49152;
+constexpr long long PACE_EMPTY_MIN_WGS = 4096;
+
+// ---- occupancy targets ------------------------------------------------------------------------------------------------------
+// waves per SIMD the 1024-thread slab variants (whole rows of 65 ... 128 voxels: 9 ... 16 waves) are compiled for: 8 = 64
+// registers, two or three workgroups per unit (D = 72: 4.16 TB/s against 3.75 with 4 = 128 registers, one workgroup)
+constexpr int BIG_WAVES_PER_SIMD = 8;
+constexpr int DIRECT_WAVES_PER_SIMD = 4; // voxelize_direct_kernel: 128 registers
+
+// ---- host-side plan (plan_call in mvx_plan.hip) ---------------------------------------------------------------------------
+// bytes of pre-pass data (records, keys, feature rows, slab lines: re-read ~20 times) per voxelize launch: what stays in
+// the 256 MiB Infinity Cache. One launch over 512 cfg-2 molecules (544 MB) ran at 0.654 of peak, in two chunks at 0.755.
+constexpr double MALL_BUDGET = 288.0e6;
+// One launch for the whole call (voxelize_direct_kernel) instead of prep -> xbin -> voxelize, us per call binned / direct
+// (tools/route_rule.py): 512 workgroups, 12 000 atoms 70 / 42; 1 024 workgroups 30 / 27; 2 304 (96^3) 30 / 44; 4 096 (128^3)
+// 31 / 63; 256 ligands in one call (131 072 workgroups) 640 / 2040.
+constexpr long long DIRECT_MAX_WORKGROUPS = 1536;
+// ... and at most this many atom tests (workgroups x atoms of their molecule: every workgroup scans its molecule, ~2 us per
+// million)
+constexpr long long DIRECT_MAX_ATOM_TESTS = 16ll << 20;
+// ... several channel chunks (C > 32) scan, stage and walk once per chunk: one molecule, C = 64, one launch / binned: D = 64
+// 4000 atoms 33 / 26 us, D = 48 1700 atoms 24 / 20 (0.97 M tests), D = 32 500 atoms 13 / 18 (0.13 M)
+constexpr long long DIRECT_MAX_ATOM_TESTS_CHUNKED = 400000;
+// ... launches of more than 512 workgroups (two or three molecules per call): the later molecules' scans share compute units
+// with the first's. cfg-2 density, D = 64, C = 32: two molecules 35 / 27 us, three 47 / 33; 8-atom molecules stay (18 / 20)
+constexpr long long DIRECT_MAX_ATOM_TESTS_MANY = 300000;
+// float64 grids of more channels than this take the matrix-core slab kernel (8 or 16 channels padded to a chunk of 32 there:
+// 1.7 / 2.9 TB/s against 2.2 / 3.2 for the general loop)
+constexpr int MX64_MIN_C = 16;
+
+} // namespace mvx

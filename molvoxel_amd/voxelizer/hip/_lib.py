@@ -41,6 +41,31 @@ class MvxXform(C.Structure):
     ]
 
 
+class MvxPlanQuery(C.Structure):
+    _fields_ = [
+        ("dimension", C.c_int32),
+        ("blockdim", C.c_int32),
+        ("precision", C.c_int32),
+        ("mode", C.c_int32),
+        ("radii_type", C.c_int32),
+        ("B", C.c_int32),
+        ("C", C.c_int32),
+        ("out_aligned16", C.c_int32),
+        ("total_atoms", C.c_int64),
+        ("max_atoms", C.c_int64),
+    ]
+
+
+class MvxPlan(C.Structure):
+    _fields_ = [(name, C.c_int32) for name in (
+        "route", "nsx", "nsy", "nzc", "nw", "ct", "ncc", "nfull", "ct_rem", "nchunk", "pace", "grouped", "lane_range",
+        "vec_store", "xcd_ranges", "cpad", "weights_in_place", "reserved")]
+
+
+MVX_ROUTE_BINNED, MVX_ROUTE_DIRECT, MVX_ROUTE_F64_DENSE, MVX_ROUTE_F64_MX, MVX_ROUTE_SPLAT = 0, 1, 2, 3, 4
+MODES = {"features": 0, "types": 1, "single": 2}
+RADII = {"scalar": MVX_RADII_SCALAR, "atom-wise": MVX_RADII_ATOM, "channel-wise": MVX_RADII_CHANNEL}
+
 Handle = C.c_void_p
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 
@@ -65,6 +90,7 @@ SIGNATURES = {
     "mvx_last_kernel_ms": (C.c_int, [Handle, C.POINTER(C.c_float)]),
     "mvx_debug_read_records": (C.c_int, [Handle, _vp, _i64, _vp]),
     "mvx_debug_set_option": (C.c_int, [Handle, C.c_char_p, _i32]),
+    "mvx_plan_call": (C.c_int, [C.POINTER(MvxPlanQuery), C.POINTER(MvxPlan)]),
     "mvx_alloc": (C.c_int, [Handle, _i64, C.POINTER(C.c_void_p)]),
     "mvx_free": (C.c_int, [Handle, _vp]),
     "mvx_memcpy": (C.c_int, [Handle, _vp, _vp, _i64, _i32, _i32, _vp]),
@@ -98,6 +124,16 @@ def check(rc: int):
     if rc != 0:
         msg = load().mvx_last_error()
         raise RuntimeError(f"libmvx_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def plan_call(dimension, C_, B=1, total_atoms=0, max_atoms=None, mode="features", radii_type="scalar", precision=32,
+              blockdim=8, out_aligned16=True) -> dict:
+    """How libmvx_hip would execute a call of this shape (mvx_plan_call: a pure host function, no GPU needed)."""
+    q = MvxPlanQuery(dimension, blockdim, precision, MODES[mode], RADII[radii_type], B, C_, 1 if out_aligned16 else 0,
+                     total_atoms, total_atoms if max_atoms is None else max_atoms)
+    p = MvxPlan()
+    check(load().mvx_plan_call(C.byref(q), C.byref(p)))
+    return {name: getattr(p, name) for name, _ in MvxPlan._fields_ if name != "reserved"}
 
 
 def device_count() -> int:

@@ -3,7 +3,7 @@
 RNG-order and arithmetic-order compatible with the reference (molvoxel/voxelizer/numpy/_quaternion.py:13-50):
 a uniform unit quaternion from three np.random.rand draws, rotation as q * (0, p) * q^-1 evaluated
 with the same products and the same left-to-right sums, so seeded results are identical. The device
-applies the same expression tree in fp64 (csrc/mvx_kernels.hip: apply_xform).
+applies the same expression tree in fp64 (csrc/mvx_device.h: apply_xform).
 """
 from __future__ import annotations
 

@@ -67,15 +67,17 @@ def cfg2(batch: int = 1, n_atoms: int = 4000, channels: int = 32, dimension: int
     return w
 
 
-def cfg3(n_atoms: int = 1000, seed: int = 3) -> Workload:
-    """Binary forward_types, 4 channels, 48^3, N=1000 (bit-exact check)."""
+def cfg3(n_atoms: int = 1000, seed: int = 3, batch: int = 1) -> Workload:
+    """Binary forward_types, 4 channels, 48^3, N=1000 (bit-exact check). Molecule 0 is the BASELINE seed-3 molecule;
+    molecules i>0 use seed + 1000*i."""
     w = Workload("cfg3", 48, 0.5, "binary", 0.5, "scalar", "types", 4)
     W = _width(0.5, 48)
-    rng = np.random.default_rng(seed)
-    w.coords.append(rng.uniform(-W / 2, W / 2, (n_atoms, 3)))
-    w.channels.append(rng.integers(0, 4, n_atoms))
-    w.radii.append(1.0)
-    w.centers.append(np.zeros(3))
+    for i in range(batch):
+        rng = np.random.default_rng(seed + 1000 * i)
+        w.coords.append(rng.uniform(-W / 2, W / 2, (n_atoms, 3)))
+        w.channels.append(rng.integers(0, 4, n_atoms))
+        w.radii.append(1.0)
+        w.centers.append(np.zeros(3))
     return w
 
 

@@ -191,7 +191,7 @@ def test_c_abi_direct_host_pointers(mv):
     from oracle import c_oracle
 
     lib = _lib.load()
-    assert lib.mvx_version() == 130  # MVX_VERSION of include/mvx.h
+    assert lib.mvx_version() == 140  # MVX_VERSION of include/mvx.h
     wl = W.cfg3()
     cfg = _lib.MvxConfig(0.5, 0.5, 48, 8, _lib.MVX_BINARY, 0, 32, 0)
     h = _lib.Handle()
@@ -877,14 +877,16 @@ def test_overlapped_prepass_equals_serial_calls(mv):
 
 @pytest.mark.parametrize("C_,distinct,D,blockdim", [(32, 4, 32, None), (40, 2, 32, None), (12, 9, 24, None), (32, 1, 32, None),
                                                     (7, 3, 27, 5), (64, 8, 16, None), (33, 33, 16, None), (32, 32, 24, None),
-                                                    (70, 31, 16, None)])
+                                                    (70, 31, 16, None), (40, 40, 16, None), (96, 96, 16, None), (45, 45, 20, 5)])
 @pytest.mark.parametrize("density", ["gaussian", "binary"])
 def test_channel_wise_features_grouped_by_radius(mv, C_, distinct, D, blockdim, density):
     """Channel-wise radii for features (numpy/voxelizer.py:213-224): channels that share a radius share the membership test
-    and the density. The batched pipeline numbers the distinct radii on the device (up to 32 slots) and evaluates one
-    threshold test and one density per slot and candidate on the matrix-core path; more distinct radii (33 here) fall
-    back to the per-channel kernel. Every shape against the oracle, and batched (grouped) against per-molecule calls
-    (direct kernel, per-channel) bit for bit; chunks of 32 channels that hold several slots, slots that span chunks."""
+    and the density. chan_aux_kernel numbers the distinct radii of every chunk of 32 channels on the device (slots, by
+    descending radius: at most 32 per chunk, so any number of channels and of distinct radii - 40 / 40, 96 / 96 here - runs
+    grouped; there is no per-channel kernel any more) and the grouped launch evaluates one threshold test and one density
+    per slot and candidate on the matrix-core path, stopping at the first slot no lane hits. Every shape against the
+    oracle, and batched against per-molecule calls bit for bit (both grouped: channel-wise features never take the
+    one-launch route); chunks that hold several slots, radii that recur in several chunks."""
     from oracle import c_oracle
 
     rng = np.random.default_rng(1000 * C_ + distinct)

@@ -104,7 +104,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/mvx.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
     loaded = _lib.load()
-    assert loaded.mvx_version() == 130
+    assert loaded.mvx_version() == 140
     # struct layouts the ABI promises
     assert C.sizeof(_lib.MvxConfig) == 40 and C.sizeof(_lib.MvxXform) == 80
 
@@ -224,7 +224,7 @@ def test_header_is_valid_c_and_matches_the_python_structs(tmp_path):
     subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     out = subprocess.check_output([str(exe)]).decode().split()
     assert [int(v) for v in out] == [C.sizeof(_lib.MvxConfig), C.sizeof(_lib.MvxXform), _lib.MvxConfig.precision.offset,
-                                     _lib.MvxXform.trans.offset, _lib.MvxXform.flags.offset, 130]
+                                     _lib.MvxXform.trans.offset, _lib.MvxXform.flags.offset, 140]
 
 
 def _build_c_demo(tmp_path):

@@ -11,34 +11,34 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OBJ = os.path.join(ROOT, "molvoxel_amd", "csrc", "mvx_kernels.o")
 
 
 @pytest.fixture(scope="module")
 def res():
-    if not os.path.exists(OBJ):
-        pytest.skip("mvx_kernels.o not built (python -c 'import __graft_entry__ as g; g.build()')")
     from tools import regs
 
-    return regs.kernel_resources(OBJ)
+    if not all(os.path.exists(o) for o in regs.KERNEL_OBJECTS):
+        pytest.skip("kernel objects not built (python -c 'import __graft_entry__ as g; g.build()')")
+    return regs.kernel_resources()
 
 
 def test_batched_voxelize_kernels_fit_their_occupancy(res):
     ks = {k: v for k, v in res.items() if k.startswith("voxelize_kernel<") and ", 512, " in k}
-    assert len(ks) >= 30
+    assert len(ks) >= 24
     for name, r in ks.items():
         assert r["vgpr"] <= 64, (name, r)  # 8 waves per SIMD
     # the headline kernel (32 channels, gaussian, matrix-core walk) and its binary twin: no scratch in the first round
-    for name in ("voxelize_kernel<32, true, false, false, 512, false>", "voxelize_kernel<32, false, false, false, 512, false>"):
+    for name in ("voxelize_kernel<32, true, false, 512, false>", "voxelize_kernel<32, false, false, 512, false>"):
         assert res[name]["scratch"] <= 32 and res[name]["vspill"] <= 6, (name, res[name])
     # narrower chunks (ligand batches, forward_types, forward_single): none at all
     for ct in (1, 4, 8, 16):
         for gauss in ("true", "false"):
-            r = res[f"voxelize_kernel<{ct}, {gauss}, false, false, 512, false>"]
+            r = res[f"voxelize_kernel<{ct}, {gauss}, false, 512, false>"]
             assert r["scratch"] == 0 and r["vspill"] == 0, (ct, gauss, r)
-    # per-lane-range variants (blockdim 4, 5, 12, ...): a handful of spills in the cold rounds, never the accumulators
+    # per-lane-range variants (blockdim 4, 5, 12, ...) and the grouped launch (channel-wise radii): a handful of spills in
+    # the cold rounds, never the accumulators
     for name, r in ks.items():
-        if name.startswith("voxelize_kernel<32,") and ", false, true, 512, false>" in name:
+        if name.startswith("voxelize_kernel<32,"):
             assert r["vspill"] <= 16 and r["scratch"] <= 80, (name, r)
 
 
@@ -46,10 +46,10 @@ def test_whole_row_slabs_of_long_rows_keep_two_workgroups_per_unit(res):
     """Rows of 65 ... 128 voxels stay in one slab of 9 ... 16 waves (plan_slabs): the 1024-thread variants are compiled for
     64 registers so that two or three such workgroups fit a compute unit (D = 72: 4.16 against 3.75 TB/s with 128)."""
     ks = {k: v for k, v in res.items() if (k.startswith("voxelize_kernel<") and ", 1024, " in k) or k.startswith("voxelize_runs_kernel<")}
-    assert len(ks) >= 30
+    assert len(ks) >= 24
     for name, r in ks.items():
         assert r["vgpr"] <= 64, (name, r)
-    for name in ("voxelize_kernel<32, true, false, false, 1024, false>", "voxelize_kernel<32, false, false, false, 1024, false>"):
+    for name in ("voxelize_kernel<32, true, false, 1024, false>", "voxelize_kernel<32, false, false, 1024, false>"):
         assert res[name]["scratch"] <= 32 and res[name]["vspill"] <= 6, (name, res[name])
 
 
@@ -75,3 +75,11 @@ def test_prepass_kernels_do_not_spill_vector_registers(res):
     for name, r in res.items():
         if name.startswith("xbin_kernel<"):
             assert r["vspill"] == 0 and r["scratch"] == 0, (name, r)
+
+
+def test_no_per_channel_float32_kernels_are_left(res):
+    """Channel-wise radii for features run grouped by radius, one table per chunk of 32 channels (at most 32 distinct radii
+    per chunk): the per-channel kernels of rounds 1-3 (200 spilled registers at 32 channels) are gone, and with them every
+    float32 instantiation that carried a `chanwise` parameter."""
+    assert sum(k.startswith("voxelize_kernel<") for k in res) == 48  # 5 widths x {gaussian, binary} x {plain, lane ranges} x 2 sizes + 8 grouped
+    assert sum(k.startswith("voxelize_direct_kernel<") for k in res) == 20

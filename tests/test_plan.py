@@ -1,0 +1,145 @@
+"""The library's decision table (mvx_plan_call: route, slab plan, channel / molecule chunks, pacing, write-out path) pinned row
+by row next to the measurements that chose each row (molvoxel_amd/csrc/mvx_tuning.h, profiles/r03_odd_dimensions.txt,
+profiles/r03_round_pacing.txt, profiles/r04_splat.txt). mvx_plan_call is a pure host function: no GPU is needed, nothing is launched.
+A change of the rule must come with the measurement that justifies moving a row."""
+import pytest
+
+from molvoxel_amd.voxelizer.hip import _lib
+
+BINNED, DIRECT, F64_DENSE, F64_MX, SPLAT = 0, 1, 2, 3, 4
+
+
+def plan(D, C, B=1, atoms=None, **kw):
+    """atoms: per molecule (default: cfg-2 density, 4000 atoms in 31.5^3 A^3 scaled to the grid's volume)"""
+    if atoms is None:
+        atoms = int(round(4000 * ((D - 1) / 63.0) ** 3))
+    return _lib.plan_call(D, C, B, total_atoms=B * atoms, max_atoms=atoms, **kw)
+
+
+def test_baseline_configurations():
+    # cfg-2, the headline: 256 pockets per call, one chunk of 32 channels on whole-row slabs, paced write-out rounds
+    p = plan(64, 32, 256, 4000)
+    assert (p["route"], p["nsx"], p["nsy"], p["nzc"], p["nw"], p["ct"], p["ncc"], p["nchunk"], p["pace"]) == (BINNED, 32, 16, 1, 8, 32, 1, 1, 2)
+    assert p["weights_in_place"] == 1 and p["vec_store"] == 1 and p["lane_range"] == 0 and p["ct_rem"] == 0
+    # one cfg-2 pocket per forward() call: 512 workgroups, one launch (19 against 21 us binned)
+    assert plan(64, 32, 1, 4000)["route"] == DIRECT
+    # cfg-1 ligand and cfg-3 (binary types, 48^3, N = 1000) as single calls: one launch
+    assert plan(64, 5, 1, 33)["route"] == DIRECT
+    assert plan(48, 4, 1, 1000, mode="types")["route"] == DIRECT
+    # cfg-5: 128^3, one call = 4096 workgroups -> binned, rows of 512 B cut in two (D % 32 == 0 keeps chunks of 8 waves)
+    p = plan(128, 32, 1, 10000, radii_type="atom-wise")
+    assert (p["route"], p["nw"], p["nzc"], p["nsx"], p["nsy"], p["pace"]) == (BINNED, 8, 2, 64, 32, 0)
+    # cfg-4 x 128 ligands per GPU: 65 536 workgroups of 16 channels, empty slabs and rounds paced
+    p = plan(64, 16, 128, 50)
+    assert (p["route"], p["ct"], p["pace"]) == (BINNED, 16, 2)
+
+
+def test_route_rule_rows():
+    """profiles/r03_odd_dimensions.txt, ROUTE_SWEEP / SMALL_BATCH_SWEEP / ONE_SWEEP tables (us per call one launch / binned)."""
+    # rows cut in two (D = 65 ... 76) never take the one-launch route: 57 / 23, 65 / 24, 69 / 27 us
+    for D in (68, 72, 76):
+        assert plan(D, 32)["route"] == BINNED
+        assert plan(D, 32, atoms=8)["route"] == BINNED
+    # several channel chunks: one launch only up to 0.4 M atom tests - C = 64 pocket at D = 64 33 / 26 us -> binned,
+    # 8 atoms 18 / 20 -> one launch, D = 24 / 32 dense 11 / 18 -> one launch
+    assert plan(64, 64, 1, 4000)["route"] == BINNED
+    assert plan(64, 64, 1, 8)["route"] == DIRECT
+    assert plan(24, 64)["route"] == DIRECT
+    # two or three large molecules per call (more than 512 workgroups): 35 / 27 and 48 / 33 us -> binned; 8-atom molecules stay
+    assert plan(64, 32, 2, 4000)["route"] == BINNED
+    assert plan(64, 32, 3, 4000)["route"] == BINNED
+    assert plan(64, 32, 2, 8)["route"] == DIRECT
+    assert plan(64, 32, 3, 8)["route"] == DIRECT
+    # beyond 1 536 workgroups always binned (4 molecules: 61 / 39 us; 256 ligands in one call 2.04 / 0.64 ms)
+    assert plan(64, 32, 4, 8)["route"] == BINNED
+    assert plan(64, 16, 256, 50)["route"] == BINNED
+    # 96^3 and 128^3 single calls: 2 304 / 4 096 workgroups, 44 / 30 and 63 / 31 us
+    assert plan(96, 32)["route"] == BINNED
+    # channel-wise radii for features: always the grouped launch of the binned pipeline, chunks of 32 channels
+    p = plan(64, 40, 1, 4000, radii_type="channel-wise")
+    assert (p["route"], p["grouped"], p["ct"], p["ncc"], p["weights_in_place"], p["ct_rem"]) == (BINNED, 1, 32, 2, 1, 0)
+    # ... but channel-wise radii for types are per-atom radii (numpy/voxelizer.py:284-285): nothing special
+    assert plan(64, 8, 1, 4000, mode="types", radii_type="channel-wise")["grouped"] == 0
+
+
+def test_slab_plans_for_long_rows():
+    """plan_slabs, profiles/r03_odd_dimensions.txt ROW_SWEEP: rows of 65 ... 128 voxels stay whole (9 ... 16 waves) unless
+    D % 32 == 0 - D = 72 1.80 -> 4.16 TB/s, 88 1.94 -> 4.02, 104 2.12 -> 4.03, 120 2.25 -> 3.81; 96 / 128 keep chunks of 8."""
+    for D, nw, nzc in ((64, 8, 1), (48, 6, 1), (50, 7, 1), (65, 9, 1), (72, 9, 1), (88, 11, 1), (104, 13, 1), (120, 15, 1), (96, 8, 2),
+                       (128, 8, 2), (100, 13, 1)):
+        p = plan(D, 32, 16)
+        assert (p["nw"], p["nzc"]) == (nw, nzc), (D, p)
+    # beyond 128: rows that are not multiples of 64 B in as few equal chunks as 16 waves allow (D = 136 1.90 -> 2.10 TB/s),
+    # multiples of 64 B keep chunks of 8 (D = 144 3.36 against 2.54-2.67)
+    assert (plan(136, 32, 16)["nw"], plan(136, 32, 16)["nzc"]) == (9, 2)
+    assert (plan(200, 16, 16)["nw"], plan(200, 16, 16)["nzc"]) == (13, 2)
+    assert (plan(144, 32, 16)["nw"], plan(144, 32, 16)["nzc"]) == (8, 3)
+    # the one-launch route and float64 grids keep at most 8 waves per slab
+    assert plan(72, 32, 16, precision=64)["nw"] == 8
+
+
+def test_channel_chunks_and_remainders():
+    # C = 33: 32 on the wide kernel + 1 on the narrowest (0.66 -> 0.57 ms per 64 molecules); C = 40: 32 + 8; C = 48: 32 + 16
+    for C, nfull, ct_rem, cpad in ((33, 1, 1, 36), (36, 1, 4, 36), (40, 1, 8, 40), (48, 1, 16, 48), (65, 2, 1, 68), (72, 2, 8, 72)):
+        p = plan(64, C, 64, 4000)
+        assert (p["ct"], p["nfull"], p["ct_rem"], p["cpad"]) == (32, nfull, ct_rem, cpad), (C, p)
+    # a remainder of more than half a chunk needs the wide kernel anyway: one launch of two chunks
+    p = plan(64, 50, 64, 4000)
+    assert (p["ncc"], p["nfull"], p["ct_rem"], p["cpad"], p["weights_in_place"]) == (2, 2, 0, 64, 0)
+    # C = 64: rows read in place
+    assert plan(64, 64, 64, 4000)["weights_in_place"] == 1
+    # types / single never read caller rows in place
+    assert plan(64, 8, 64, 4000, mode="types")["weights_in_place"] == 0
+
+
+def test_infinity_cache_chunks_and_grid_limits():
+    # 256 cfg-2 molecules are one chunk (272 MB of re-read data fits the 288 MB budget); 512 / 1024 are cut (0.654 -> 0.755 of peak)
+    assert plan(64, 32, 256, 4000)["nchunk"] == 1
+    assert plan(64, 32, 512, 4000)["nchunk"] == 2
+    assert plan(64, 32, 1024, 4000)["nchunk"] == 4
+    # gridDim.y limit: 65 535 (molecule, chunk) pairs per launch
+    assert plan(16, 64, 40000, 4)["nchunk"] >= 2
+
+
+def test_pacing_thresholds():
+    """mvx_tuning.h: rounds paced from 49 152 workgroups (96 cfg-2 molecules: 64 molecules lose 3-5 % in short bursts, 128
+    gain 3 %), empty slabs held back beyond 4 096."""
+    assert plan(64, 32, 8, 4000)["pace"] == 0
+    assert plan(64, 32, 16, 4000)["pace"] == 1
+    assert plan(64, 32, 64, 4000)["pace"] == 1
+    assert plan(64, 32, 96, 4000)["pace"] == 2
+    assert plan(64, 32, 256, 4000)["pace"] == 2
+
+
+def test_write_out_paths():
+    # rows that are not whole 16-byte quads, or an unaligned grid slice: run-wise write-out, one slab range per XCD on whole-row grids
+    p = plan(50, 32, 64)
+    assert (p["vec_store"], p["xcd_ranges"]) == (0, 1)
+    p = plan(64, 32, 64, out_aligned16=False)
+    assert (p["vec_store"], p["xcd_ranges"]) == (0, 1)
+    p = plan(130, 32, 4)
+    assert (p["vec_store"], p["xcd_ranges"]) == (0, 0)
+    # sub-tile edges (2, 4, 8) divide blockdim 8 / 16 / 64, not 4 / 5 / 12; a single block needs no cull at all
+    for bd, lr in ((8, 0), (16, 0), (64, 0), (4, 1), (5, 1), (12, 1)):
+        assert plan(64, 32, 64, blockdim=bd)["lane_range"] == lr
+    assert plan(16, 8, 1, blockdim=20)["lane_range"] == 0
+
+
+def test_float64_routes():
+    # more than 16 channels with scalar / atom-wise radii: chunks of 32 on the matrix cores (3.65 -> 4.6 TB/s)
+    p = plan(64, 32, 64, 4000, precision=64)
+    assert (p["route"], p["ct"], p["ncc"]) == (F64_MX, 32, 1)
+    p = plan(64, 16, 64, 4000, precision=64)
+    assert (p["route"], p["ct"]) == (F64_DENSE, 16)
+    p = plan(64, 32, 64, 4000, precision=64, radii_type="channel-wise")
+    assert (p["route"], p["ct"], p["ncc"], p["grouped"]) == (F64_DENSE, 16, 2, 0)
+
+
+def test_query_validation():
+    import ctypes as C
+
+    lib = _lib.load()
+    q = _lib.MvxPlanQuery(0, 8, 32, 0, 0, 1, 1, 1, 0, 0)
+    p = _lib.MvxPlan()
+    assert lib.mvx_plan_call(C.byref(q), C.byref(p)) != 0
+    assert lib.mvx_plan_call(None, C.byref(p)) != 0

@@ -5,9 +5,13 @@ name=$1; flags=$2
 cd "$(dirname "$0")/../molvoxel_amd/csrc"
 mkdir -p ab
 F="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-pass-failed -Wno-bitwise-instead-of-logical $flags"
-/opt/rocm/bin/hipcc $F -c -o ab/k_$name.o mvx_kernels.hip &
-/opt/rocm/bin/hipcc $F -c -o ab/c_$name.o mvx_capi.hip &
+objs=""
+for tu in capi plan prep slab direct f64 splat; do
+  [ -f mvx_$tu.hip ] || continue
+  /opt/rocm/bin/hipcc $F -c -o ab/${tu}_$name.o mvx_$tu.hip &
+  objs="$objs ab/${tu}_$name.o"
+done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/libmvx_$name.so ab/k_$name.o ab/c_$name.o
-rm -f ab/k_$name.o ab/c_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/libmvx_$name.so $objs
+rm -f $objs
 echo built ab/libmvx_$name.so

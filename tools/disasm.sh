@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/disasm.sh <mangled-name-substring> [object] [lines] -> /tmp/kernel.s (the kernel's ISA), prints where scratch / barriers / loads / stores sit
-obj=${2:-/root/repo/molvoxel_amd/csrc/mvx_kernels.o}
+obj=${2:-/root/repo/molvoxel_amd/csrc/mvx_slab.o}
 L=/opt/rocm/lib/llvm/bin
 cd /tmp && $L/llvm-objcopy --dump-section=.hip_fatbin=/tmp/fat.bin $obj /tmp/ign && $L/clang-offload-bundler --unbundle --type=o --input=/tmp/fat.bin --output=/tmp/k.co --targets=hipv4-amdgcn-amd-amdhsa--gfx950 && $L/llvm-objdump -d --no-show-raw-insn /tmp/k.co > /tmp/k.s
 S=$(grep -n "^[0-9a-f]* <.*$1" /tmp/k.s | head -1 | cut -d: -f1)

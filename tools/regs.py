@@ -1,16 +1,25 @@
 """Register / LDS / scratch use of every kernel in a built object or library, read from the gfx950 code object's metadata.
 
-    python3 tools/regs.py [path/to/lib.so or .o] [substring ...]      default: molvoxel_amd/csrc/mvx_kernels.o
+    python3 tools/regs.py [path/to/lib.so or .o] [substring ...]      default: every kernel object of molvoxel_amd/csrc
 """
 import os, re, subprocess, sys, tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT_OBJ = os.path.join(ROOT, "molvoxel_amd/csrc/mvx_kernels.o")
+CSRC = os.path.join(ROOT, "molvoxel_amd/csrc")
+KERNEL_OBJECTS = [os.path.join(CSRC, f"mvx_{name}.o") for name in ("prep", "slab", "direct", "f64", "splat")
+                  if os.path.exists(os.path.join(CSRC, f"mvx_{name}.hip"))]
 
 
-def kernel_resources(obj=DEFAULT_OBJ):
-    """{demangled kernel name (without 'void mvx::' and the argument list): dict(vgpr, sgpr, vspill, sspill, scratch, lds)}"""
+def kernel_resources(obj=None):
+    """{demangled kernel name (without 'void mvx::' and the argument list): dict(vgpr, sgpr, vspill, sspill, scratch, lds)}
+    obj = None: every kernel object of the library (one per kernel family)."""
+    if obj is None:
+        out = {}
+        for o in KERNEL_OBJECTS:
+            if os.path.exists(o):
+                out.update(kernel_resources(o))
+        return out
     with tempfile.TemporaryDirectory() as td:
         co, fat = os.path.join(td, "k.co"), os.path.join(td, "fat.bin")
         subprocess.check_call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj, os.path.join(td, "ignored")])
@@ -32,7 +41,7 @@ def kernel_resources(obj=DEFAULT_OBJ):
 
 
 if __name__ == "__main__":
-    obj = sys.argv[1] if len(sys.argv) > 1 and os.path.exists(sys.argv[1]) else DEFAULT_OBJ
+    obj = sys.argv[1] if len(sys.argv) > 1 and os.path.exists(sys.argv[1]) else None
     pats = [a for a in sys.argv[1:] if not os.path.exists(a)]
     for short, r in sorted(kernel_resources(obj).items()):
         if pats and not any(p in short for p in pats):
