@@ -349,6 +349,28 @@ def test_medium_density_multi_round_slab_lines(mv):
     assert_gaussian(outg, refg)  # sums of up to ~60 terms
 
 
+@pytest.mark.parametrize("D,C_,blockdim", [(70, 16, None), (120, 16, None), (70, 32, 5), (120, 32, 5), (72, 32, None), (100, 8, None)])
+def test_whole_row_slabs_of_long_rows_with_more_than_64_candidates(mv, D, C_, blockdim):
+    """Rows of 65 ... 128 voxels stay in one slab of 9 ... 16 waves (plan_slabs). A round still holds 64 rows: the staging
+    step's slot wave + u * NW runs past 63 for the larger u there and must skip those slots (a guard the 8-wave kernels do
+    not need) - slabs with 64 ... 255 candidates (radius 2.0 A on the 0.5 A grid) take several rounds over line and
+    extension. Batched (binned route), Gaussian and binary, against the oracle."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(D * 100 + C_)
+    W_ = 0.5 * (D - 1)
+    n = int(9000 * (D / 70.0) ** 3)  # ~150 candidates per slab at a 2.0 A radius
+    xyz = rng.uniform(-W_ / 2, W_ / 2, (n, 3))
+    f = rng.random((n, C_)).astype(np.float32)
+    extra = {"blockdim": blockdim} if blockdim else {}
+    for density in ("gaussian", "binary"):
+        v = mv.create_voxelizer(0.5, D, "scalar", density, "hip", output="numpy", sigma=0.7, **extra)
+        v.debug_option("direct", 0)
+        out = v.forward(xyz, None, f, 2.0)
+        ref = c_oracle.voxelize(xyz, f, 2.0, dimension=D, density=density, sigma=0.7, blockdim=blockdim)
+        assert_gaussian(out, ref)  # (binary features too: sums of ~150 float32 products, the relative branch of the rule)
+
+
 def test_long_x_list_beyond_lds_copy(mv):
     """An x-slab list longer than the binning pass's LDS copy (1024 entries): its tail is re-read from L2."""
     from oracle import c_oracle
