@@ -718,6 +718,8 @@ struct OpsF32 {
     static constexpr bool RUNS = LANE_RANGE; // carries the run-wise write-out (store_runs)
     static constexpr int CT = CT_;
     static constexpr bool GROUPED = false;
+    static constexpr bool VSTAGE = false;
+    static constexpr bool CULL = true;
     typedef float2v Acc[(CT + 1) / 2];
     static constexpr int WORDS = 1;                   // 32-bit words per channel weight
     static constexpr int WW = CT;                     // weight words staged per row
@@ -856,6 +858,42 @@ __device__ __forceinline__ void stage_round(const uint2 *__restrict__ line, cons
     }
 }
 
+// The same round for narrow rows (16 record words + at most 16 weight words: OpsPair), with every address formed on the vector
+// ALU: the round's 64 line entries arrive with ONE load (entry e0 + lane), every lane picks the atom of its row slot with
+// ds_bpermute, and a load instruction fetches two rows (lanes 0-31 / 32-63). Four row loads per wave instead of eight, and
+// none of stage_round's scalar work (eight s_loads, eight 64-bit scalar multiply-adds, the per-slot branches): the narrow
+// launches are bound by the compute unit's one scalar unit, not - like the 32-channel kernel, which keeps the scalar path -
+// by a vector memory pipeline full of stores.
+template <typename Ops, bool BIG>
+__device__ __forceinline__ void stage_round_v(const uint2 *__restrict__ line, const uint2 *__restrict__ ext, int e0, int n_line,
+                                              unsigned *un, const unsigned *__restrict__ rec, const unsigned *__restrict__ w, int64_t a0,
+                                              int lane, int wave, int NW, const LaneCtx &L, const VoxParams &P) {
+    constexpr int SW = Ops::SW;
+    const int e = e0 + lane;
+    int ai = 0;
+    if (e >= 1 && e <= n_line) ai = (int)(e < SLOTS ? line[e].x : ext[e - SLOTS].x);
+    const int half = lane >> 5, wd = lane & 31;
+    const bool used = wd < 16 + Ops::WW;
+    const unsigned *base = wd < 16 ? rec + wd : w + (L.cbase + wd - 16);
+    const unsigned stride = wd < 16 ? 16u : (unsigned)P.w_stride; // (32-bit operands: one v_mad_u64_u32 per row address)
+    const unsigned first = (unsigned)a0;                          // (atom indices fit 31 bits: validate())
+    const int lo = 1 - e0, hi = n_line - e0; // slot sl holds a candidate iff lo <= sl <= hi (and sl < 64)
+    unsigned v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int sl = wave + NW * (2 * u + half); // this lane's row slot <-> entry e0 + sl
+        const unsigned a = (unsigned)__builtin_amdgcn_ds_bpermute(4 * sl, ai); // (slots beyond the round read some other lane's entry: masked)
+        const bool in = sl >= lo && sl <= hi && (!BIG || sl < 64) && used;
+        v[u] = 0u;
+        if (in) v[u] = base[(size_t)(first + a) * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int sl = wave + NW * (2 * u + half);
+        if (sl >= lo && sl <= hi && (!BIG || sl < 64) && used) un[sl * SW + wd] = v[u];
+    }
+}
+
 // One lane per staged row decides whether this wave walks it; then the walk. xl (workgroup-uniform, rare): the entries
 // come from a (molecule, x-slab) list instead of a slab line (LINE_OVERFLOW slabs, below): they have not been filtered
 // against the slab's y rows, so the row filter also tests the record's admitted y range.
@@ -869,7 +907,7 @@ __device__ __forceinline__ void filter_walk(const bool xl, typename Ops::Acc &ac
         const unsigned *r = un + lane * SW;
         const unsigned zr = r[12];
         ok = ((int)((zr & 0xffff) >> SUBZ_SH) <= L.zt_w) && ((int)((zr >> 16) >> SUBZ_SH) >= L.zt_w);
-        ok = ok && reaches_subtile(r, lane, L, P);
+        if constexpr (Ops::CULL) ok = ok && reaches_subtile(r, lane, L, P);
         if (xl) {
             const unsigned yr = r[11];
             const int sy = L.iy >> SUBY_SH; // (the slab's y index: the same for every lane)

@@ -163,6 +163,8 @@ struct OpsMx64 {
     static constexpr bool RUNS = false;
     static constexpr int CT = 32;
     static constexpr bool GROUPED = false;
+    static constexpr bool VSTAGE = false;
+    static constexpr bool CULL = true;
     struct Acc {
         d4v a[2][4]; // [channel block of 16][voxel block m = 2 x + yh]: channels 16 cb + 4 r + lane / 16, r = 0..3
     };

@@ -57,6 +57,8 @@ struct OpsMx32 {
     static constexpr int CT = 32;
     static constexpr bool RUNS = RUNS_; // carries the run-wise write-out (store_runs)
     static constexpr bool GROUPED = GROUPED_;
+    static constexpr bool VSTAGE = false;
+    static constexpr bool CULL = true;
     struct Acc {
         f16v p0, p1; // the x0 plane and the x0 + 1 plane of the sub-tile
     };
@@ -233,16 +235,126 @@ struct OpsMx32 {
     }
 };
 
-// voxelize_kernel's arithmetic: 32-channel chunks go to the matrix cores (OpsMx32), everything else to the vector ALU
+// ---- narrow chunks (1 ... 16 channels) on the vector ALU, two candidates per step ---------------------------------------
+// forward_single, forward_types with a few element channels, cfg-1's 5 and cfg-4's 16 feature channels: little to store, so
+// the walk is what such launches cost - and with one voxel per lane (OpsF32) they were bound by the compute unit's one
+// scalar unit (304 scalar against 237 vector instructions per wave at C = 1, scalar issue 80 % busy:
+// profiles/r04_narrow.txt) with the vector ALU close behind. OpsPair keeps OpsF32's accumulators (one voxel per lane, CT
+// channels: same write-out) but EVALUATES like OpsMx32: lanes 0-31 take candidate A, lanes 32-63 candidate B of a pair, each
+// lane for the two voxels (x0, ly, lz) and (x0 + 1, ly, lz) - dy^2 and dz^2 shared: 14 float64 operations per pair
+// instead of 18, one trip of the scalar loop per pair instead of two. v_permlane32_swap then hands every lane the two
+// candidates' values at its OWN voxel (lanes 32-63 own the x0 + 1 plane), and the accumulators take them in candidate
+// order: acc = fma(vA, wA, acc), then fma(vB, wB, acc) - bit for bit OpsF32's chain (a missing second candidate adds
+// fma(0, w, acc) = acc). Its rows (<= 32 words) are staged two per load instruction with addresses formed on the
+// vector ALU (stage_round_v): the eight scalar index loads and 64-bit scalar address computations per wave were
+// half of the scalar instructions.
+template <int CT_, bool GAUSS>
+struct OpsPair {
+    static constexpr int CT = CT_;
+    static constexpr bool RUNS = false;
+    static constexpr bool GROUPED = false;
+    static constexpr bool VSTAGE = true;
+    // no per-wave sphere / box cull of the staged rows (reaches_subtile): ~35 vector instructions per wave and round to drop
+    // 1-2 of a wave's ~8 candidates at 17 (Gaussian) or 12 (binary) instructions each - same box, culled -> not culled,
+    // kernel: forward_single 0.121 -> 0.118 ms, 8 types 0.173 -> 0.167, cfg-3 x 256 0.238 -> 0.217 (profiles/r04_narrow.txt)
+    static constexpr bool CULL = false;
+    typedef float2v Acc[(CT + 1) / 2];
+    static constexpr int WORDS = 1;
+    static constexpr int WW = CT < 4 ? 4 : CT;       // weight words staged per row (prep pads rows of fewer than 4 channels)
+    static constexpr int SW = cand_stride_words(CT); // row stride in LDS, words
+    static_assert(16 + WW <= 32, "two rows per load instruction");
+    static __device__ __forceinline__ void zero(Acc &acc) {
+#pragma unroll
+        for (int c = 0; c < (CT + 1) / 2; ++c) acc[c] = (float2v){0.0f, 0.0f};
+    }
+    static __device__ __forceinline__ LaneCtx ctx(int lane, int wave, int x0, int y0, int z0, int zt_lo, int cbase, const VoxParams &P) {
+        const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1);
+        LaneCtx L;
+        L.ix = x0; // (x0 is a multiple of SUBX: every lane evaluates the x0 and the x0 + 1 plane)
+        L.iy = y0 + ly;
+        L.iz = z0 + SUBZ * wave + lz;
+        L.gx = (double)L.ix * P.res - P.half;
+        L.gx1 = (double)(L.ix + 1) * P.res - P.half;
+        L.gy = (double)L.iy * P.res - P.half;
+        L.gz = (double)L.iz * P.res - P.half;
+        L.zt_w = zt_lo + wave;
+        L.cbase = cbase;
+        return L;
+    }
+    static __device__ __forceinline__ void tables(LaneCtx &, char *, const VoxParams &, int) {}
+    static __device__ __forceinline__ void walk(Acc &acc, unsigned long long mask, const unsigned *un, int lane, const LaneCtx &L,
+                                                const VoxParams &, const double *__restrict__, const float *__restrict__) {
+        const bool upper = lane >= 32; // this lane evaluates the pair's second candidate
+        while (mask) {
+            const int s0 = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const bool two = mask != 0; // (uniform)
+            int s1 = s0;
+            if (two) {
+                s1 = __builtin_ctzll(mask);
+                mask &= mask - 1;
+            }
+            const bool valid = !upper || two;
+            const unsigned *r = un + (upper ? s1 : s0) * SW;
+            const double2 Pxy = *reinterpret_cast<const double2 *>(r);     // px, py
+            const double2 PzT = *reinterpret_cast<const double2 *>(r + 4); // pz, T
+            const double dx0 = Pxy.x - L.gx, dx1 = Pxy.x - L.gx1, dy = Pxy.y - L.gy, dz = PzT.x - L.gz;
+            const double dy2 = dy * dy, dz2 = dz * dz;
+            const double d2a = (dx0 * dx0 + dy2) + dz2; // cdist order, no fma
+            const double d2b = (dx1 * dx1 + dy2) + dz2;
+            const bool hita = valid && d2a <= PzT.y, hitb = valid && d2b <= PzT.y;
+            float va, vb;
+            if (GAUSS) {
+                const float k = __uint_as_float(r[8]);
+                va = hita ? __builtin_amdgcn_exp2f(k * (float)d2a) : 0.0f;
+                vb = hitb ? __builtin_amdgcn_exp2f(k * (float)d2b) : 0.0f;
+            } else {
+                va = hita ? 1.0f : 0.0f;
+                vb = hitb ? 1.0f : 0.0f;
+            }
+            // lanes 32-63 of the first register <-> lanes 0-31 of the second: afterwards v0 / v1 hold the first / second
+            // candidate's value at the voxel THIS lane accumulates (x0 plane in lanes 0-31, x0 + 1 plane in lanes 32-63)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+            const float v0 = __uint_as_float(sw[0]), v1 = __uint_as_float(sw[1]);
+            const float *f0 = reinterpret_cast<const float *>(un + s0 * SW + 16), *f1 = reinterpret_cast<const float *>(un + s1 * SW + 16);
+            if constexpr (CT == 1) {
+                acc[0].x = fmaf(v0, f0[0], acc[0].x);
+                acc[0].x = fmaf(v1, f1[0], acc[0].x);
+            } else {
+                const float2v p0 = (float2v){v0, v0}, p1 = (float2v){v1, v1};
+#pragma unroll
+                for (int c = 0; c < CT / 2; ++c) acc[c] = __builtin_elementwise_fma(p0, *reinterpret_cast<const float2v *>(f0 + 2 * c), acc[c]);
+#pragma unroll
+                for (int c = 0; c < CT / 2; ++c) acc[c] = __builtin_elementwise_fma(p1, *reinterpret_cast<const float2v *>(f1 + 2 * c), acc[c]);
+            }
+        }
+    }
+    static __device__ __forceinline__ void write(const Acc &acc, bool any, unsigned *un, int tid, int lane, int wave, int NW,
+                                                 int b, const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
+        write_slab<CT, false>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
+                              static_cast<float *>(out), P);
+    }
+};
+
+// voxelize_kernel's arithmetic: 32-channel chunks go to the matrix cores (OpsMx32), narrower chunks to the vector ALU in
+// candidate pairs (OpsPair); the per-lane-range variants keep one voxel per lane and candidate (OpsF32)
 template <int CT, bool GAUSS, bool LANE_RANGE, bool GROUPED>
 struct SlabOps {
     typedef OpsF32<CT, GAUSS, LANE_RANGE> type;
 };
+template <int CT, bool GAUSS>
+struct SlabOps<CT, GAUSS, false, false> {
+    typedef OpsPair<CT, GAUSS> type;
+};
 // (not the per-lane-range variants - blockdim 4, 5, 12, ...: their six extra index comparisons per voxel do not fit the
 // 64 registers of the two-voxel layout without scratch: 0.527 against 0.479 ms per 64 cfg-2 molecules at blockdim 5)
-template <bool GAUSS, bool GROUPED>
-struct SlabOps<32, GAUSS, false, GROUPED> {
-    typedef OpsMx32<GAUSS, false, GROUPED> type;
+template <bool GAUSS>
+struct SlabOps<32, GAUSS, false, false> {
+    typedef OpsMx32<GAUSS, false, false> type;
+};
+template <bool GAUSS>
+struct SlabOps<32, GAUSS, false, true> {
+    typedef OpsMx32<GAUSS, false, true> type;
 };
 // (grouped launches - channel-wise features by radius - exist on the matrix-core path only, per-lane ranges or not)
 template <bool GAUSS>
