@@ -87,20 +87,24 @@ def cpu_baseline(budget_s: float):
 
 def parity_spot(out, coords, feats, picks, radius=1.0, dimension=64, sigma=0.5):
     """Post-timing spot check (outside the timed region): the grids of the molecules `picks` of the batch that was
-    just timed against the CPU oracle: membership identical, |d| <= 1e-5 absolute on every voxel (the north-star bar,
-    tests/tolerance.py). Returns "ok" or "FAIL: ..."."""
+    just timed against the CPU oracle: membership identical and, on every voxel, BOTH bars - the suite's relative rule
+    |d| <= 5e-6 * max(1, |ref|) and the north-star's |d| <= 1e-5 absolute (tests/tolerance.py), i.e. the smaller of the two.
+    Returns ("ok" or "FAIL: ...", worst |d| seen)."""
     from oracle import c_oracle
 
+    worst_all = 0.0
     for b in picks:
         ref = c_oracle.voxelize(coords[b], feats[b], radius, dimension=dimension, sigma=sigma)
         got = out[b].cpu().numpy()
         bad = int(np.not_equal(got != 0, ref != 0).sum())
         if bad:
-            return f"FAIL: molecule {b}: membership differs in {bad} voxels"
-        worst = float(np.abs(got - ref).max())
-        if worst > 1e-5:
-            return f"FAIL: molecule {b}: max |out - ref| = {worst:.3g} > 1e-5"
-    return "ok"
+            return f"FAIL: molecule {b}: membership differs in {bad} voxels", None
+        d = np.abs(got - ref)
+        worst_all = max(worst_all, float(d.max()))
+        over = d > np.minimum(5e-6 * np.maximum(1.0, np.abs(ref)), 1e-5)
+        if over.any():
+            return f"FAIL: molecule {b}: {int(over.sum())} voxels beyond min(5e-6 * max(1, |ref|), 1e-5); max |out - ref| = {float(d.max()):.3g}", worst_all
+    return "ok", worst_all
 
 
 def load_pmc_traffic(molecules_per_launch: int):
@@ -193,7 +197,7 @@ def make_cfg4_shard(total: int, rank: int, world: int):
     return wl, lo, hi
 
 
-# Fixed pre-warm, disclosed in the JSON line (`prewarm_launches`). On a box that has been idle the kernel settles in two
+# Default pre-warm (--prewarm N overrides), disclosed in the JSON line (`prewarm_launches`). On a box that has been idle the kernel settles in two
 # stages: the first ~15 launches run up to 18 % slower, and the next ~100 still 2-3 % slower (cold box, 30 + 5 warm-up
 # launches: kernel 1.425-1.445 ms; the same command a minute later: 1.390-1.417 ms). 200 launches = 0.3 s per rank.
 PREWARM_LAUNCHES = 200
@@ -302,6 +306,14 @@ class Ranks:
         self.dist.all_reduce(seen)
         return mx, [float(v.item()) for v in every], int(seen.item())
 
+    def gather_objects(self, obj):
+        """every rank's small record (device identity, kernel time), in rank order - over gloo"""
+        if self.dist is None:
+            return [obj]
+        every = [None] * self.world
+        self.dist.all_gather_object(every, obj)
+        return every
+
     def close(self):
         if self.dist is not None:
             self.dist.barrier()
@@ -349,6 +361,8 @@ def main():
                     help="auto (N = 1, cfg2): measure roofline.traffic in this run with two child rocprofv3 --pmc passes "
                          "(~30 s); if that is not possible, or off: the committed profiles/pmc_latest.json figure, labelled as replayed")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--prewarm", type=int, default=PREWARM_LAUNCHES,
+                    help="untimed launches before the counted warm-up (clock ramp; ~1.5 ms each at the default batch)")
     ap.add_argument("--rehearse", action="store_true",
                     help="plumbing only: launcher, rendezvous, barrier, MAX, one JSON line - no GPU work, not a measurement")
     args = ap.parse_args()
@@ -417,7 +431,7 @@ def main():
     # Pass 1 - what `value` and `ms_per_step` come from: no profiling events anywhere near the launches.
     # A fixed pre-warm precedes the counted warm-up: the first ~15 launches after an idle period run up to 18 % slower
     # (clock ramp), and a caller's small --warmup should not decide whether the timed steps sit on that ramp.
-    for _ in range(PREWARM_LAUNCHES):
+    for _ in range(max(0, args.prewarm)):
         step()
     for _ in range(args.warmup):
         step()
@@ -446,11 +460,23 @@ def main():
     kernel_ms = vox.read_kernel_times_ms()
     vox.set_profiling(False)
 
+    # who ran where, and how fast its kernel was: a scaling efficiency below par can then be pinned on a rank / a device
+    props = torch.cuda.get_device_properties(dev_index)
+    bus = getattr(props, "pci_bus_id", None)
+    me = {"rank": rank, "device_index": dev_index, "device": props.name,
+          "pci": None if bus is None else f"{getattr(props, 'pci_domain_id', 0):04x}:{bus:02x}:{getattr(props, 'pci_device_id', 0):02x}",
+          "uuid": str(getattr(props, "uuid", "")), "ms_per_step": 1e3 * my_elapsed / args.steps,
+          "kernel_ms_avg": float(np.mean(kernel_ms)) if kernel_ms else None}
+    per_rank = ranks.gather_objects(me)
+    # ranks that share a device do not measure an N-GPU job: the line says so and carries no `value`
+    distinct = len({(r["uuid"], r["pci"], r["device_index"]) for r in per_rank})
+    devices_shared = distinct < world
+
     # post-timing spot check of the grids the timed steps left behind (rank 0, outside the timed region)
-    spot = None
+    spot, spot_worst = None, None
     if rank == 0:
         picks = sorted({0, B // 2, B - 1})
-        spot = parity_spot(out, coords, feats, picks)
+        spot, spot_worst = parity_spot(out, coords, feats, picks)
 
     if rank == 0:
         # the library cuts a step's batch into equal chunks of molecules only beyond 65535 (molecule, channel chunk)
@@ -476,14 +502,16 @@ def main():
         res = {
             "metric": "molecules/sec + achieved HBM GB/s, forward_features C=32 64^3 N=4000" if args.workload == "cfg2"
                       else "molecules/sec, batch of ligands (cfg-4), forward_features C=16 64^3 N~50",
-            "value": job_molecules * args.steps / elapsed,
+            "value": None if devices_shared else job_molecules * args.steps / elapsed,
             "unit": "molecules/s",
             "n_gpus": args.gpus,
+            "devices_shared": devices_shared,
+            "distinct_devices": distinct,
             "ranks_seen": ranks_seen,
             "collective_backend": ranks.backend,
             "steps": args.steps,
             "warmup": args.warmup,
-            "prewarm_launches": PREWARM_LAUNCHES,
+            "prewarm_launches": max(0, args.prewarm),
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
@@ -523,8 +551,14 @@ def main():
                 "traffic_source": traffic_source,
             },
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+            "per_rank": per_rank,
             "parity_spot": spot,
+            "parity_spot_max_abs": spot_worst,
         }
+        if devices_shared:  # (a rehearsal of the N-rank code path on fewer GPUs: the aggregate is NOT an N-GPU figure)
+            res["shared_device_molecules_per_s"] = job_molecules * args.steps / elapsed
+            res["note"] = (f"{world} ranks on {distinct} device(s): ranks share GPUs, so `value` is withheld; "
+                           "shared_device_molecules_per_s is what the shared device(s) delivered")
         if ranks.note:
             res["collective_note"] = ranks.note
         if args.gpus == 1 and args.cpu_seconds > 0 and args.workload == "cfg2":

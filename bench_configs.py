@@ -132,13 +132,38 @@ def pcie_inclusive(steps=5):
     return dict(config="cfg2 x8, numpy in -> numpy out (PCIe inclusive)", molecules_per_s=8 * steps / el, ms_per_molecule=1e3 * el / steps / 8)
 
 
+def pacing_rows(steps=40, warmup=60):
+    """Guard rows for the pacing thresholds (mvx_tuning.h: write-out rounds paced from 49 152 workgroups = 96 cfg-2
+    molecules, empty slabs held back beyond 4 096): cfg-2 at 16 / 64 / 96 / 256 molecules per call and cfg-4 x 128, kernel
+    TB/s of algorithmic bytes. Re-run whenever the slab kernels change: a threshold that has drifted shows up as a dip at
+    64 -> 96 or as cfg-4 falling below ~0.8 of peak (round 3: 0.715 / 0.785 / 0.80 / 0.80 of peak, cfg-4 0.85)."""
+    from molvoxel_amd import workloads as W
+
+    rows = []
+    w2 = W.cfg2(batch=256)
+    for b in (16, 64, 96, 256):
+        r = run(f"pacing guard: cfg2 x{b}", w2, list(range(b)), steps, warmup)
+        r["of_peak"] = r["GBps"] / 8000.0
+        rows.append(r)
+    w4 = W.cfg4(batch=128)
+    r = run("pacing guard: cfg4 ligands x128", w4, list(range(128)), steps, warmup)
+    r["of_peak"] = r["GBps"] / 8000.0
+    rows.append(r)
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--pacing", action="store_true", help="only the pacing guard rows (cfg-2 x 16 / 64 / 96 / 256, cfg-4 x 128)")
     ap.add_argument("--harness", action="store_true", help="also run the test_time_numpy.py loop (16 x 25 x 5) on the hip backend")
     args = ap.parse_args()
     from molvoxel_amd import workloads as W
 
+    if args.pacing:
+        for r in pacing_rows():
+            print(json.dumps(r))
+        return
     rows = []
     pc = np.load(os.path.join(ROOT, "tests", "golden", "pointcloud_10gs.npz"))
     w1 = W.cfg1(pc["ligand_xyz"], pc["ligand_feat5"])
@@ -146,8 +171,9 @@ def main():
     w2 = W.cfg2(batch=64)
     rows.append(run("cfg2 N=4000 C=32 64^3 (single call)", w2, [0], args.steps))
     rows.append(run("cfg2 N=4000 C=32 64^3 x64", w2, list(range(64)), args.steps))
-    w3 = W.cfg3()
+    w3 = W.cfg3(batch=256)
     rows.append(run("cfg3 binary types 4ch 48^3 (single call)", w3, [0], args.steps))
+    rows.append(run("cfg3 binary types 4ch 48^3 x256", w3, list(range(256)), args.steps))
     w4 = W.cfg4(batch=128)
     rows.append(run("cfg4 ligands C=16 64^3 x128", w4, list(range(128)), args.steps))
     w5 = W.cfg5(batch=4)

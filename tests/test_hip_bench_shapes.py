@@ -117,6 +117,22 @@ def test_bench_spot_check_helper():
     out, *_ = _batch_call(vox, wl, [0, 1, 2])
     coords = [wl.coords[i] for i in range(3)]
     feats = [wl.channels[i] for i in range(3)]
-    assert bench.parity_spot(out, coords, feats, picks=(0, 2)) == "ok"
+    verdict, worst = bench.parity_spot(out, coords, feats, picks=(0, 2))
+    assert verdict == "ok" and 0 < worst <= 5e-6
     out[2, 5, 10, 10, 10] += 1.0
-    assert bench.parity_spot(out, coords, feats, picks=(0, 2)).startswith("FAIL")
+    assert bench.parity_spot(out, coords, feats, picks=(0, 2))[0].startswith("FAIL")
+
+
+def test_pacing_guard_rows_are_recorded(record_property):
+    """The store pacing of the slab kernels is tuned to launch shapes (mvx_tuning.h): this test records - it does not
+    assert a rate, boxes of the pool differ by +-2 % and short runs sit on the clock ramp - the kernel's fraction of the
+    HBM peak at cfg-2 x 16 / 64 / 96 / 256 and cfg-4 x 128, so that a drifted threshold is visible in the test report
+    (`bench_configs.py --pacing` is the same table with settled clocks). Only gross cliffs fail it."""
+    import bench_configs
+
+    rows = bench_configs.pacing_rows(steps=10, warmup=30)
+    for r in rows:
+        record_property(r["config"], round(r["of_peak"], 3))
+        print(f'{r["config"]}: kernel {r["kernel_ms"]:.3f} ms = {r["of_peak"]:.3f} of peak')
+    by = {r["config"]: r["of_peak"] for r in rows}
+    assert by["pacing guard: cfg2 x256"] > 0.6 and by["pacing guard: cfg2 x64"] > 0.55 and by["pacing guard: cfg4 ligands x128"] > 0.6

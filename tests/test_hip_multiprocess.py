@@ -74,8 +74,26 @@ def test_bench_py_two_rank_code_path(workload, extra):
     assert len(lines) == 1, "rank 0 prints exactly one JSON line"
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["scaling"] == "weak" and rec["parity_spot"] == "ok"
-    assert rec["value"] > 0 and rec["rank_ms_per_step"]["max"] >= rec["rank_ms_per_step"]["min"] > 0
+    _check_shared_device_line(rec, 2)
+    assert rec["rank_ms_per_step"]["max"] >= rec["rank_ms_per_step"]["min"] > 0
     assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1.2
+
+
+def _check_shared_device_line(rec, n):
+    """On this 1-GPU box the ranks share the card: the line must say so and must NOT carry a `value` (an aggregate over
+    ranks that share a GPU is not an N-GPU measurement); every rank reports where it ran and its kernel time."""
+    import torch
+
+    shared = torch.cuda.device_count() < n
+    assert rec["devices_shared"] == shared and rec["distinct_devices"] == (1 if shared else n)
+    if shared:
+        assert rec["value"] is None and rec["shared_device_molecules_per_s"] > 0 and "share" in rec["note"]
+    else:
+        assert rec["value"] > 0
+    assert [r["rank"] for r in rec["per_rank"]] == list(range(n))
+    for r in rec["per_rank"]:
+        assert r["kernel_ms_avg"] > 0 and r["ms_per_step"] > 0 and r["device"] and r["device_index"] >= 0
+    assert rec["parity_spot_max_abs"] is not None and rec["parity_spot_max_abs"] <= 1e-5
 
 
 def _bare_bench(args, timeout=900):
@@ -92,13 +110,14 @@ def test_bare_bench_py_starts_its_own_ranks_on_the_hip_path(n, extra):
     """The driver's N-GPU command without the launcher (`python3 bench.py --gpus N ...`): one JSON line, every rank
     counted, parity spot check green. On this 1-GPU box the ranks share the device (at most 4 here: the pool allows six
     processes on a card) and rendezvous over gloo; the 8-rank form is rehearsed without GPU work in test_bench_helpers.py."""
-    res = _bare_bench(["--gpus", str(n), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"] + extra)
+    res = _bare_bench(["--gpus", str(n), "--steps", "2", "--warmup", "1", "--prewarm", "5", "--cpu-seconds", "0"] + extra)
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
     lines = res.stdout.splitlines()
     assert len(lines) == 1 and lines[0].startswith("{"), res.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == n and rec["ranks_seen"] == n and rec["parity_spot"] == "ok" and rec["scaling"] == "weak"
-    assert rec["collective_backend"] in ("gloo", "nccl") and rec["value"] > 0 and rec["prewarm_launches"] >= 1
+    assert rec["collective_backend"] in ("gloo", "nccl") and rec["prewarm_launches"] >= 1
+    _check_shared_device_line(rec, n)
     assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1.2
 
 
