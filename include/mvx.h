@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MVX_VERSION 140 /* 0.1.4: mvx_plan_call (the decision table as a pure function), the narrow-channel splat route; 0.1.3: one voxelize launch per batched call, channel-wise radii grouped on the device; 0.1.2: mvx_xform.center_ptr, stream hand-over, unaligned out, mvx_debug_set_option */
+#define MVX_VERSION 140 /* 0.1.4: mvx_plan_call (the decision table as a pure function), channel-wise radii grouped per chunk of 32 channels, narrow chunks in candidate pairs; 0.1.3: one voxelize launch per batched call, channel-wise radii grouped on the device; 0.1.2: mvx_xform.center_ptr, stream hand-over, unaligned out, mvx_debug_set_option */
 
 typedef enum mvx_status {
     MVX_OK = 0,
@@ -229,8 +229,7 @@ enum mvx_route {
     MVX_ROUTE_BINNED = 0,    /* prep -> xbin -> voxelize_kernel (slab lines; the batched float32 pipeline) */
     MVX_ROUTE_DIRECT = 1,    /* voxelize_direct_kernel: the whole call in one launch (per-molecule calls) */
     MVX_ROUTE_F64_DENSE = 2, /* float64 grids, general slab loop */
-    MVX_ROUTE_F64_MX = 3,    /* float64 grids, 32-channel chunks on the matrix cores */
-    MVX_ROUTE_SPLAT = 4      /* prep -> cbin -> voxelize_splat_kernel: narrow channel counts, atom-centric accumulation in LDS */
+    MVX_ROUTE_F64_MX = 3     /* float64 grids, 32-channel chunks on the matrix cores */
 };
 typedef struct mvx_plan_query {
     int32_t dimension;
@@ -246,7 +245,7 @@ typedef struct mvx_plan_query {
 typedef struct mvx_plan {
     int32_t route;            /* enum mvx_route */
     int32_t nsx, nsy, nzc;    /* slabs along x, along y, z chunks of a row */
-    int32_t nw;               /* waves per slab: a slab is 2 x 4 x (8 nw) voxels (splat: 8 x 8 x (8 nw)) */
+    int32_t nw;               /* waves per slab: a slab is 2 x 4 x (8 nw) voxels */
     int32_t ct, ncc;          /* channels per workgroup, channel chunks */
     int32_t nfull, ct_rem;    /* chunks of the main launch; width of the remainder launch's kernel (0: none) */
     int32_t nchunk;           /* molecule chunks (gridDim.y limit, Infinity Cache budget, "chunks" option) */

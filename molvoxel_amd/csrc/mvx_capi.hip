@@ -893,7 +893,6 @@ int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
     if (n == "chunks") k.pipeline = std::max(1, std::min(16, (int)value));
     else if (n == "max_ct") k.max_ct = std::max(1, std::min(32, (int)value));
     else if (n == "direct") k.direct_mode = value < 0 ? -1 : (value ? 1 : 0);
-    else if (n == "splat") k.splat_mode = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "max_ct64") k.max_ct64 = value >= 32 ? 32 : 16;
     else if (n == "dense_grid") (void)value; // (accepted and ignored: there is no second voxelize launch any more)
     else if (n == "nw") k.force_nw = (value >= 1 && value <= 16) ? value : 0; // waves (8-voxel z sub-tiles) per slab; 0 = the default plan

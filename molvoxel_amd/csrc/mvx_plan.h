@@ -17,7 +17,6 @@ struct PlanKnobs {
     int32_t max_ct64 = 32;    // float64 grids: 32 = matrix-core chunks where they apply
     int32_t direct_mode = -1; // -1: the rule; 0 / 1: never / always the one-launch route (where it applies)
     int32_t pipeline = 1;     // > 1: molecule chunks with the pre-pass on a side stream
-    int32_t splat_mode = -1;  // -1: the rule; 0 / 1: never / always the narrow-channel splat kernel (where it applies)
     double mall_budget = MALL_BUDGET;
 };
 

@@ -62,7 +62,7 @@ class MvxPlan(C.Structure):
         "vec_store", "xcd_ranges", "cpad", "weights_in_place", "reserved")]
 
 
-MVX_ROUTE_BINNED, MVX_ROUTE_DIRECT, MVX_ROUTE_F64_DENSE, MVX_ROUTE_F64_MX, MVX_ROUTE_SPLAT = 0, 1, 2, 3, 4
+MVX_ROUTE_BINNED, MVX_ROUTE_DIRECT, MVX_ROUTE_F64_DENSE, MVX_ROUTE_F64_MX = 0, 1, 2, 3
 MODES = {"features": 0, "types": 1, "single": 2}
 RADII = {"scalar": MVX_RADII_SCALAR, "atom-wise": MVX_RADII_ATOM, "channel-wise": MVX_RADII_CHANNEL}
 

@@ -1,12 +1,12 @@
 """The library's decision table (mvx_plan_call: route, slab plan, channel / molecule chunks, pacing, write-out path) pinned row
 by row next to the measurements that chose each row (molvoxel_amd/csrc/mvx_tuning.h, profiles/r03_odd_dimensions.txt,
-profiles/r03_round_pacing.txt, profiles/r04_splat.txt). mvx_plan_call is a pure host function: no GPU is needed, nothing is launched.
+profiles/r03_round_pacing.txt). mvx_plan_call is a pure host function: no GPU is needed, nothing is launched.
 A change of the rule must come with the measurement that justifies moving a row."""
 import pytest
 
 from molvoxel_amd.voxelizer.hip import _lib
 
-BINNED, DIRECT, F64_DENSE, F64_MX, SPLAT = 0, 1, 2, 3, 4
+BINNED, DIRECT, F64_DENSE, F64_MX = 0, 1, 2, 3
 
 
 def plan(D, C, B=1, atoms=None, **kw):

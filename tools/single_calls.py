@@ -40,6 +40,9 @@ else:
     chan = vox.asarray(wl.channels[0], wl.mode)
     radii = wl.radii[0] if np.isscalar(wl.radii[0]) else vox.asarray(wl.radii[0], "radii")
     C_ = wl.num_channels
+for opt in ("direct",):  # route switch: DIRECT=0 python3 tools/single_calls.py cfg2
+    if os.environ.get(opt.upper()) is not None:
+        vox.debug_option(opt, int(os.environ[opt.upper()]))
 if os.environ.get("MVX_DBG"):  # diagnostic builds: run-time ablations of the direct kernel
     vox.debug_option("dbg", int(os.environ["MVX_DBG"]))
 if os.environ.get("MVX_MAX_CT"):  # narrower chunks: more, lighter workgroups per call
