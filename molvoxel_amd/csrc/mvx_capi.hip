@@ -93,6 +93,7 @@ struct mvx_handle {
     hipStream_t side = nullptr;
     hipEvent_t ev_in = nullptr;
     std::vector<hipEvent_t> ev_pre;
+    int narrow_sub = 0; // "narrow_sub" option: sub-tiles per wave of narrow chunks (1: voxelize_kernel; 2 | 4: voxelize_narrow_kernel; 0: the rule)
     int dbg = 0; // diagnostic builds (-DMVX_DIAG) only
 };
 
@@ -513,6 +514,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.Tc = d_Tc;
     va.kc = d_kc;
     va.out = d_out;
+    va.narrow_sub = h->narrow_sub;
     va.p.res = g.res;
     va.p.half = g.half;
     va.p.D = D;
@@ -894,6 +896,7 @@ int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value) {
     else if (n == "max_ct") k.max_ct = std::max(1, std::min(32, (int)value));
     else if (n == "direct") k.direct_mode = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "max_ct64") k.max_ct64 = value >= 32 ? 32 : 16;
+    else if (n == "narrow_sub") h->narrow_sub = (value == 1 || value == 2 || value == 4) ? value : 0;
     else if (n == "dense_grid") (void)value; // (accepted and ignored: there is no second voxelize launch any more)
     else if (n == "nw") k.force_nw = (value >= 1 && value <= 16) ? value : 0; // waves (8-voxel z sub-tiles) per slab; 0 = the default plan
     else if (n == "mall_budget_kb") k.mall_budget = value > 0 ? 1024.0 * (double)value : MALL_BUDGET;

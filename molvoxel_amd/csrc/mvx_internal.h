@@ -128,6 +128,7 @@ struct VoxArgs {
     const double *Tc;      // channel-wise features: per-channel d2 thresholds (float64 grids: the radii themselves)
     const float *kc;       //                        per-channel gaussian coefficients
     void *out;             // (B, C, D, D, D) float, or double for float64 grids
+    int32_t narrow_sub;    // test / A-B switch ("narrow_sub"): sub-tiles per wave of narrow chunks - 1 (voxelize_kernel), 2, 4; 0 = the rule
     VoxParams p;
 };
 

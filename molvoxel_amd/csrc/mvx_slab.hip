@@ -371,6 +371,174 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : BIG_WAVES_PER_SIMD))
 #include "mvx_slab_body.inc"
 }
 
+// ---- voxelize_narrow_kernel: narrow chunks with NSUB (2 or 4) sub-tiles per wave -------------------------------------------
+// What is left of a narrow launch after OpsPair is per-wave fixed cost: at cfg-3 density a wave walks two or three candidate
+// pairs (~85 vector instructions) around ~110 of prologue, staging, row filter and write-out, and as many scalar ones. Here a
+// slab of NS sub-tiles is served by NS / NSUB waves: wave w owns sub-tiles NSUB w ... NSUB w + NSUB - 1 - one prologue, one
+// share of the staging (rows two per load, vector-ALU addresses, as stage_round_v), then filter + pair walk once per
+// sub-tile (OpsPair::walk with that sub-tile's z coordinate) into NSUB accumulator sets, and one write-out. Same candidates,
+// same order, same arithmetic per voxel as voxelize_kernel<CT < 32>: bit-identical grids. At most 8 waves per workgroup
+// whatever the row length (16 sub-tiles: 128 voxels), so there is no 1024-thread variant. Same box, one -> two sub-tiles
+// per wave, kernel: forward_single 0.118 -> 0.109 ms, 8 types 0.173 -> 0.162, cfg-3 x 256 0.219 -> 0.164 (profiles/r04_narrow.txt).
+// Waves per SIMD the kernel is compiled for: its natural register need with two sub-tiles is 66 / 72 / 80 for 1 / 4 / 8
+// channels (accumulator sets, eight row loads in flight); at the 64 of voxelize_kernel it spilled 1 ... 17 registers.
+// (16 channels: 96 registers and no gain over one sub-tile per wave, 0.228 ms both - they keep voxelize_kernel.)
+constexpr int narrow_waves_per_simd(int ct, int nsub) { return ct * nsub <= 8 ? 7 : (ct * nsub <= 16 && nsub == 2 ? 6 : 5); }
+template <int CT, bool GAUSS, int NSUB>
+__global__ void __launch_bounds__(512, narrow_waves_per_simd(CT, NSUB))
+    voxelize_narrow_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
+                           const uint2 *__restrict__ slist_ext, float *__restrict__ out, const VoxParams P) {
+    typedef OpsPair<CT, GAUSS> Ops;
+    constexpr int SW = Ops::SW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned *un = reinterpret_cast<unsigned *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NS = P.NW, NWV = NS / NSUB; // sub-tiles per slab, waves per workgroup
+
+    unsigned t = blockIdx.x;
+    if (P.nzc > 1) { // consecutive blocks = consecutive x-slabs (mvx_slab_body.inc)
+        const unsigned per_x = (unsigned)(P.nsy * P.nzc), nsx = (unsigned)P.nsx;
+        t = (t % nsx) * per_x + t / nsx;
+    }
+    int b = (int)blockIdx.y, cc = 0;
+    if (P.ncc > 1) {
+        b = (int)blockIdx.y / P.ncc;
+        cc = (int)blockIdx.y - b * P.ncc;
+    }
+    b += P.b0;
+    const uint2 *__restrict__ line = slist + ((size_t)b * (size_t)gridDim.x + t) * SLOTS; // (uniform: scalar loads)
+    const uint2 hdr = line[0];
+    int sx, sy, zc;
+    decode_slab(t, P, sx, sy, zc);
+    const int x0 = SUBX * sx, y0 = SUBY * sy, z0 = zc * SUBZ * NS;
+    const int cbase = P.c0 + cc * CT;
+    // voxel centres: both sub-tiles share x and y and differ in z only
+    LaneCtx L0 = Ops::ctx(lane, NSUB * wave, x0, y0, z0, zc * NS, cbase, P);
+    double gz[NSUB];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) gz[s] = (double)(L0.iz + SUBZ * s) * P.res - P.half;
+    typename Ops::Acc acc[NSUB];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) Ops::zero(acc[s]);
+
+    const unsigned n_hdr = __builtin_amdgcn_readfirstlane(hdr.x);
+    const unsigned first = __builtin_amdgcn_readfirstlane(hdr.y); // the molecule's first atom (atom indices fit 31 bits)
+    if (n_hdr > 0) {
+        const bool xl = __builtin_expect(n_hdr > (unsigned)LINE_CAP, 0); // the slab walks its (molecule, x-slab) list (mvx_slab_body.inc)
+        const uint2 *__restrict__ ext = slist_ext + ((size_t)b * (size_t)gridDim.x + t) * EXT_SLOTS;
+        int n = (int)n_hdr;
+        if (xl) {
+            const uint2 where = line[1];
+            const unsigned long long at = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)where.y) << 32) |
+                                          (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)where.x);
+            typedef const uint2 __attribute__((address_space(1))) *global_u2;
+            const global_u2 xlp = (global_u2)at;
+            n = __builtin_amdgcn_readfirstlane((int)xlp[0].x);
+            line = (const uint2 *)(xlp + (XL_HEADER - 1));
+            ext = line + SLOTS;
+        }
+        const int half = lane >> 5, wd = lane & 31;
+        const bool used = wd < 16 + Ops::WW;
+        const unsigned *base = wd < 16 ? rec + wd : w + (cbase + wd - 16);
+        const unsigned stride = wd < 16 ? 16u : (unsigned)P.w_stride;
+        const int RW = 8 * NS < 64 ? 8 * NS : 64; // rows staged per round
+        for (int e0 = 0; e0 <= n; e0 += RW) {
+            if (e0 > 0) __syncthreads(); // every wave is done with the previous round's rows
+            {   // stage: the round's entries one per lane, rows two per load instruction
+                const int e = e0 + lane;
+                int ai = 0;
+                if (lane < RW && e >= 1 && e <= n) ai = (int)(e < SLOTS ? line[e].x : ext[e - SLOTS].x);
+                const int lo = 1 - e0, hi = n - e0; // slot sl holds a candidate iff lo <= sl <= hi and sl < RW
+                for (int ub = 0; 2 * ub * NWV < RW; ub += 8) { // (one trip for 4 waves: 8 loads in flight)
+                    unsigned v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int sl = wave + NWV * (2 * (ub + i) + half);
+                        const unsigned a = (unsigned)__builtin_amdgcn_ds_bpermute(4 * sl, ai);
+                        v[i] = 0u;
+                        if (sl >= lo && sl <= hi && sl < RW && used) v[i] = base[(size_t)(first + a) * stride];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int sl = wave + NWV * (2 * (ub + i) + half);
+                        if (sl >= lo && sl <= hi && sl < RW && used) un[sl * SW + wd] = v[i];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) { // one lane per staged row decides whether this sub-tile takes it; then the pair walk
+                bool ok = false;
+                if (lane < RW && e0 + lane >= 1 && e0 + lane <= n) {
+                    const unsigned *r = un + lane * SW;
+                    const unsigned zr = r[12];
+                    ok = ((int)((zr & 0xffff) >> SUBZ_SH) <= L0.zt_w + s) && ((int)((zr >> 16) >> SUBZ_SH) >= L0.zt_w + s);
+                    if (xl) {
+                        const unsigned yr = r[11];
+                        ok = ok && ((int)((yr & 0xffff) >> SUBY_SH) <= sy) && ((int)((yr >> 16) >> SUBY_SH) >= sy);
+                    }
+                }
+                LaneCtx Ls = L0;
+                Ls.gz = gz[s];
+                Ops::walk(acc[s], __ballot(ok), un, lane, Ls, P, nullptr, nullptr);
+            }
+        }
+    }
+
+    // ---- write-out: [channel][x, y row][z] tile, CR_F32 channels per round, read back as float4 rows of the whole slab ----
+    constexpr int CR = CT < CR_F32 ? CT : CR_F32, NROUND = CT / CR;
+    const int D = P.D, RS = row_stride_floats(NS);
+    const size_t D2 = (size_t)D * D, D3 = D2 * D;
+    const int F4 = (SUBZ / 4) * NS;          // float4 slots per row
+    const int q = tid % F4, rfirst = tid / F4; // this thread's slot and first row; rows advance by nthr / F4 = 32 / NSUB per pass
+    constexpr int CPP = 32 / NSUB / RPC;       // ... i.e. by CPP = 2 | 1 channels
+    static_assert(NSUB == 2 || NSUB == 4, "read-back passes of whole channels");
+    const int zq = z0 + 4 * q;
+    const int sxx = (rfirst >> SUBY_SH) & (SUBX - 1), syy = rfirst & (SUBY - 1), cfirst = rfirst / RPC; // cfirst < CPP
+    const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
+    float *dst0 = out + ((size_t)b * P.C + cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
+    if (n_hdr == 0) { // zero fill without the LDS round trip, held back and sent in pieces in big launches (write_slab)
+        if (P.pace) __builtin_amdgcn_s_sleep(EMPTY_HOLD);
+        if (vox_ok) {
+#pragma unroll
+            for (int p = 0; p < (CT + CPP - 1) / CPP; ++p) {
+                const int c = cfirst + CPP * p;
+                if (c < CT && cbase + c < P.C) store_f4(dst0 + (size_t)(CPP * p) * D3, make_float4(0.f, 0.f, 0.f, 0.f));
+                if (P.pace && ((p + 1) * CPP) % 8 == 0 && p + 1 < (CT + CPP - 1) / CPP) __builtin_amdgcn_s_sleep(EMPTY_SPLIT);
+            }
+        }
+        return;
+    }
+    float *tile = reinterpret_cast<float *>(un);
+    const int lz = lane & (SUBZ - 1), ly = (lane >> SUBZ_SH) & (SUBY - 1), lx = lane >> (SUBZ_SH + SUBY_SH);
+    const int rxy = lx * SUBY + ly;
+#pragma unroll
+    for (int rd = 0; rd < NROUND; ++rd) {
+        __syncthreads(); // candidate rows (round 0) / previous tile (later rounds) fully consumed
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const int col = SUBZ * (NSUB * wave + s) + lz;
+#pragma unroll
+            for (int c = 0; c < CR; ++c) {
+                const int cg = rd * CR + c;
+                tile[(c * RPC + rxy) * RS + col] = (cg & 1) ? acc[s][cg / 2].y : acc[s][cg / 2].x;
+            }
+        }
+        __syncthreads();
+        if (vox_ok) {
+#pragma unroll
+            for (int p = 0; p < (CR + CPP - 1) / CPP; ++p) {
+                const int c = cfirst + CPP * p; // channel inside the round
+                if (c < CR && cbase + rd * CR + c < P.C) {
+                    const float4 v = *reinterpret_cast<const float4 *>(tile + (rfirst + CPP * RPC * p) * RS + 4 * q);
+                    store_f4(dst0 + (size_t)(rd * CR + CPP * p) * D3, v);
+                }
+            }
+        }
+    }
+}
+
 // 32-channel chunks of float32 grids whose rows are not whole 16-byte quads (odd dimensions, unaligned grid slices): the
 // matrix-core walk with the run-wise write-out (store_runs). A kernel of its own: compiled into voxelize_kernel<32, ...>
 // the extra write-out path costs the aligned-grid kernels six more spilled registers and 0.5 % of the headline rate.
@@ -467,6 +635,24 @@ struct LaunchFn {
         static LdsLimit raised;
         constexpr bool mx = mx_kernel<CT, GAUSS, LANE_RANGE>();
         const size_t lds = mx ? voxelize_mx_lds_bytes(p.NW) : voxelize_lds_bytes(CT, p.NW, CR_F32);
+        if constexpr (CT < 16 && !LANE_RANGE) { // narrow chunks: several sub-tiles per wave (voxelize_narrow_kernel)
+            // four where the accumulator sets fit (1 or 4 channels) and the row is a multiple of four sub-tiles, else two
+            const int nsub = a.narrow_sub > 0 ? a.narrow_sub : ((CT <= 4 && p.NW % 4 == 0) ? 4 : 2);
+            if (nsub > 1 && p.NW % nsub == 0 && p.vec_store) {
+                static LdsLimit raised_n;
+                auto launch_n = [&](auto kn) {
+                    hipError_t en = raise_lds_limit(kn, lds, raised_n);
+                    if (en != hipSuccess) return en;
+                    launch_profiled(kn, dim3(slab_grid_x(p), (unsigned)(nb * p.ncc)), dim3(p.NW / nsub * 64), lds, s, a.rec, a.w, a.slist,
+                                    a.slist_ext, static_cast<float *>(a.out), a.p);
+                    return hipGetLastError();
+                };
+                if constexpr (CT <= 4) {
+                    if (nsub == 4) return launch_n(&voxelize_narrow_kernel<CT, GAUSS, 4>);
+                }
+                if (nsub == 2) return launch_n(&voxelize_narrow_kernel<CT, GAUSS, 2>);
+            }
+        }
         auto kern = &voxelize_kernel<CT, GAUSS, LANE_RANGE, MAXT>;
         LdsLimit *state = &raised;
         if (!p.vec_store) {

@@ -83,3 +83,15 @@ def test_no_per_channel_float32_kernels_are_left(res):
     float32 instantiation that carried a `chanwise` parameter."""
     assert sum(k.startswith("voxelize_kernel<") for k in res) == 48  # 5 widths x {gaussian, binary} x {plain, lane ranges} x 2 sizes + 8 grouped
     assert sum(k.startswith("voxelize_direct_kernel<") for k in res) == 20
+
+
+def test_narrow_kernels_hold_their_accumulator_sets_in_registers(res):
+    """voxelize_narrow_kernel (1 ... 8 channels, two or four sub-tiles per wave): compiled for 7 / 6 / 5 waves per SIMD so that
+    the NSUB accumulator sets and the eight row loads in flight stay in registers (at voxelize_kernel's 64 registers it
+    spilled up to 17)."""
+    ks = {k: v for k, v in res.items() if k.startswith("voxelize_narrow_kernel<")}
+    assert len(ks) == 10  # {1, 4} channels x {2, 4} sub-tiles + 8 channels x 2, Gaussian and binary
+    for name, r in ks.items():
+        assert r["vspill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 104, (name, r)
+    for gauss in ("true", "false"):
+        assert res[f"voxelize_narrow_kernel<1, {gauss}, 2>"]["vgpr"] <= 72 and res[f"voxelize_narrow_kernel<8, {gauss}, 2>"]["vgpr"] <= 80

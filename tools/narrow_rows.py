@@ -29,6 +29,8 @@ CALLS = int(os.environ.get("CALLS", 30))
 def run(name):
     mode, C, density, D, N, B = ROWS[name]
     vox = molvoxel_amd.create_voxelizer(0.5, D, "scalar", density, library="hip")
+    if os.environ.get("NARROW_SUB"):  # A/B: sub-tiles per wave of narrow chunks (1: voxelize_kernel; 2 | 4: voxelize_narrow_kernel)
+        vox.debug_option("narrow_sub", int(os.environ["NARROW_SUB"]))
     if name == "cfg3x256":
         wl = W.cfg3(batch=B)
         xyz = np.concatenate(wl.coords)

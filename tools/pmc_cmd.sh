@@ -23,7 +23,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         agg[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in agg.items():
-    if "voxelize_kernel" not in k: continue
+    if "voxelize_kernel" not in k and "voxelize_narrow" not in k: continue
     print(k)
     m = {c: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for c, v in d.items()}  # second half of the dispatches: warmed up
     for c in sorted(m): print(f"   {c:24s} n={len(d[c]):4d} mean={m[c]:.6g}")
