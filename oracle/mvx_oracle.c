@@ -111,7 +111,6 @@ static int ovx_run(const ovx_params *p, int chan_kind, const double *coords, con
     make_axis(p, axis);
     for (int m = 1; m < nb; ++m) bounds[m - 1] = axis[m * bd] + (res / 2.0); /* voxelizer.py:55 */
 
-    memset(out, 0, sizeof(float) * (size_t)C * (size_t)D3);
 
     /* channel-wise: cull radius is the float32 max of radii (voxelizer.py:138) */
     float rmax32 = 0.0f;
@@ -149,22 +148,60 @@ static int ovx_run(const ovx_params *p, int chan_kind, const double *coords, con
 
     const float r_scalar32 = (float)r_scalar; /* np.divide(float32 array, python float) */
 
-    /* ---- accumulate: threads own (x-plane, band of y rows) tiles, atoms visited in order => deterministic.
-     *      Tiles, not whole x-planes: D planes keep at most D threads busy (64 of a 128-thread host at D = 64);
-     *      with ~4 tiles per thread every core the host offers has work. ---- */
+    /* ---- per x-plane candidate lists, in atom order (counting sort): an (x-plane, y-band) tile then visits the atoms whose
+     *      radius window and x block admit that plane instead of every atom of the molecule ---- */
+    int32_t *xlo = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+    int32_t *xhi = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+    int64_t *xstart = (int64_t *)calloc((size_t)D + 1, sizeof(int64_t));
+    for (int64_t n = 0; n < N; ++n) {
+        xlo[n] = 1;
+        xhi[n] = 0;
+        if (!keep[n]) continue;
+        double rw = (p->radii_mode == 0) ? (double)r_scalar32 : (p->radii_mode == 1 ? (double)radii[n] : (double)rmax32);
+        rw = rw * 1.0000002 + 1e-9;
+        const double px = coords[3 * n];
+        int lo = (int)floor((px - rw - axis[0]) / res) - 1, hi = (int)ceil((px + rw - axis[0]) / res) + 1;
+        if (lo < 0) lo = 0;
+        if (hi > D - 1) hi = D - 1;
+        xlo[n] = lo;
+        xhi[n] = hi;
+        for (int ix = lo; ix <= hi; ++ix) xstart[ix + 1]++;
+    }
+    for (int ix = 0; ix < D; ++ix) xstart[ix + 1] += xstart[ix];
+    int32_t *xatoms = (int32_t *)malloc(sizeof(int32_t) * (size_t)(xstart[D] > 0 ? xstart[D] : 1));
+    {
+        int64_t *fill = (int64_t *)malloc(sizeof(int64_t) * (size_t)D);
+        for (int ix = 0; ix < D; ++ix) fill[ix] = xstart[ix];
+        for (int64_t n = 0; n < N; ++n)
+            for (int ix = xlo[n]; ix <= xhi[n]; ++ix) xatoms[fill[ix]++] = (int32_t)n;
+        free(fill);
+    }
+
+    /* ---- accumulate: threads own (x-plane, band of y rows) tiles; a tile is accumulated in a thread-local buffer
+     *      [C][rows][D] (atoms visited in order => deterministic, same sums as a voxel-by-voxel loop) and written out once,
+     *      row by row: every output row is written by exactly one tile, zeros included - no memset, no strided
+     *      read-modify-write of the 33-MB grid. ~4 tiles per thread, so every core the host offers has work. ---- */
     int ytiles = 1;
 #ifdef _OPENMP
     ytiles = (4 * omp_get_max_threads() + D - 1) / D;
 #endif
     if (ytiles > (D + 3) / 4) ytiles = (D + 3) / 4;
     if (ytiles < 1) ytiles = 1;
-#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    const int rows_max = (D + ytiles - 1) / ytiles + 1;
+#pragma omp parallel
+    {
+    float *buf = (float *)malloc(sizeof(float) * (size_t)C * (size_t)rows_max * (size_t)D);
+#pragma omp for collapse(2) schedule(dynamic, 1)
     for (int ix = 0; ix < D; ++ix) {
       for (int ty = 0; ty < ytiles; ++ty) {
         const int bx = ix / bd;
         const int ty0 = (int)((int64_t)D * ty / ytiles), ty1 = (int)((int64_t)D * (ty + 1) / ytiles) - 1;
-        for (int64_t n = 0; n < N; ++n) {
-            if (!keep[n]) continue;
+        const int rows = ty1 - ty0 + 1;
+        if (rows <= 0) continue;
+        const int64_t plane = (int64_t)rows * D; /* floats per channel in the tile buffer */
+        memset(buf, 0, sizeof(float) * (size_t)C * (size_t)plane);
+        for (int64_t q = xstart[ix]; q < xstart[ix + 1]; ++q) {
+            const int64_t n = xatoms[q];
             const unsigned char *okx = okb + ((size_t)n * 3 + 0) * nb;
             const unsigned char *oky = okb + ((size_t)n * 3 + 1) * nb;
             const unsigned char *okz = okb + ((size_t)n * 3 + 2) * nb;
@@ -196,11 +233,11 @@ static int ovx_run(const ovx_params *p, int chan_kind, const double *coords, con
                     const double dz = pz - axis[iz];
                     const double d2 = dxy2 + dz * dz;       /* (dx^2 + dy^2) + dz^2, no FMA */
                     const float dist = (float)sqrt(d2);     /* cdist fp64 -> astype(float32) */
-                    const int64_t vox = ((int64_t)ix * D + iy) * D + iz;
+                    const int64_t vox = (int64_t)(iy - ty0) * D + iz; /* inside the tile */
                     if (p->radii_mode == 2) {
                         for (int c = 0; c < C; ++c) {
                             const float dr = dist / radii[c];
-                            if (dr <= 1.0f) out[(int64_t)c * D3 + vox] += feat[n * C + c] * density_value(p, dr);
+                            if (dr <= 1.0f) buf[(int64_t)c * plane + vox] += feat[n * C + c] * density_value(p, dr);
                         }
                         continue;
                     }
@@ -210,17 +247,25 @@ static int ovx_run(const ovx_params *p, int chan_kind, const double *coords, con
                     const float val = density_value(p, dr);
                     if (chan_kind == OVX_FEATURES) {
                         const float *f = feat + n * C;
-                        for (int c = 0; c < C; ++c) out[(int64_t)c * D3 + vox] += f[c] * val;
+                        for (int c = 0; c < C; ++c) buf[(int64_t)c * plane + vox] += f[c] * val;
                     } else if (chan_kind == OVX_TYPES) {
-                        out[(int64_t)types[n] * D3 + vox] += val;
+                        buf[(int64_t)types[n] * plane + vox] += val;
                     } else {
-                        out[vox] += val;
+                        buf[vox] += val;
                     }
                 }
             }
         }
+        for (int c = 0; c < C; ++c)
+            memcpy(out + (int64_t)c * D3 + ((int64_t)ix * D + ty0) * D, buf + (int64_t)c * plane, sizeof(float) * (size_t)plane);
       }
     }
+    free(buf);
+    }
+    free(xlo);
+    free(xhi);
+    free(xstart);
+    free(xatoms);
     free(axis);
     free(bounds);
     free(keep);
