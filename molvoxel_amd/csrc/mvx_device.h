@@ -374,6 +374,28 @@ __device__ __forceinline__ bool prep_atom(const PrepArgs &A, int64_t a, const do
     return keep;
 }
 
+// ---- per-molecule kernels (mvx_direct.hip, mvx_pair.hip): block cull of ONE reference block, uniform over a slab ----
+// reference block cull along one axis for the block holding voxel index v (numpy/voxelizer.py:500-513):
+// lo / hi are bounds[b-1] and bounds[b] (numpy/voxelizer.py:55), has_lo / has_hi say whether the comparison applies
+struct BlockBounds {
+    double lo, hi;
+    bool has_lo, has_hi;
+};
+__device__ __forceinline__ BlockBounds block_bounds(const Geom &g, int v) {
+    BlockBounds B;
+    int blk = v / g.bd;
+    if (blk > g.nb - 1) blk = g.nb - 1;
+    const double hres = g.res / 2.0;
+    B.has_lo = g.nb > 1 && blk >= 1;
+    B.has_hi = g.nb > 1 && blk <= g.nb - 2;
+    B.lo = uniform(((double)(blk * g.bd) * g.res - g.half) + hres);       // bounds[blk - 1]
+    B.hi = uniform(((double)((blk + 1) * g.bd) * g.res - g.half) + hres); // bounds[blk]
+    return B;
+}
+__device__ __forceinline__ bool block_admits(const BlockBounds &B, double p, double r) {
+    return (!B.has_lo || p > B.lo - r) && (!B.has_hi || p < B.hi + r);
+}
+
 // candidate lists written by xbin_kernel (mvx_prep.hip) and read by the slab kernels
 constexpr int XL_HEADER = 2;
 constexpr int XL_LDS = 1024; // x-list entries cached in LDS for pass B (8 KB; + 8 KB of lines: 8 blocks per CU); longer lists are re-read from L2

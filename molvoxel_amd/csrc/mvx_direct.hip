@@ -38,27 +38,6 @@ static size_t direct_lds_bytes(int32_t ct, int32_t NW) {
     return (size_t)NW * SEGW * 2 + DIRECT_HDR_BYTES + (un > strips ? un : strips);
 }
 
-// reference block cull along one axis for the block holding voxel index v (numpy/voxelizer.py:500-513):
-// lo / hi are bounds[b-1] and bounds[b] (numpy/voxelizer.py:55), has_lo / has_hi say whether the comparison applies
-struct BlockBounds {
-    double lo, hi;
-    bool has_lo, has_hi;
-};
-__device__ __forceinline__ BlockBounds block_bounds(const Geom &g, int v) {
-    BlockBounds B;
-    int blk = v / g.bd;
-    if (blk > g.nb - 1) blk = g.nb - 1;
-    const double hres = g.res / 2.0;
-    B.has_lo = g.nb > 1 && blk >= 1;
-    B.has_hi = g.nb > 1 && blk <= g.nb - 2;
-    B.lo = uniform(((double)(blk * g.bd) * g.res - g.half) + hres);       // bounds[blk - 1]
-    B.hi = uniform(((double)((blk + 1) * g.bd) * g.res - g.half) + hres); // bounds[blk]
-    return B;
-}
-__device__ __forceinline__ bool block_admits(const BlockBounds &B, double p, double r) {
-    return (!B.has_lo || p > B.lo - r) && (!B.has_hi || p < B.hi + r);
-}
-
 template <int CT, bool GAUSS, bool LANE_RANGE, int MAXT>
 __global__ void __launch_bounds__(MAXT, DIRECT_WAVES_PER_SIMD)
     voxelize_direct_kernel(const DirectArgs A, float *__restrict__ out, const VoxParams P) {
@@ -436,27 +415,28 @@ __global__ void __launch_bounds__(MAXT, DIRECT_WAVES_PER_SIMD)
 // ------------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------------
-template <int CT, bool GAUSS, bool LANE_RANGE>
+template <int CT, bool GAUSS>
 static hipError_t launch_direct(const DirectArgs &d, const VoxParams &p, float *out, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     if ((long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
     static LdsLimit raised;
     const size_t lds = direct_lds_bytes(CT, p.NW);
-    auto kern = &voxelize_direct_kernel<CT, GAUSS, LANE_RANGE, 512>;
+    auto kern = &voxelize_direct_kernel<CT, GAUSS, true, 512>;
     hipError_t e = raise_lds_limit(kern, lds, raised);
     if (e != hipSuccess) return e;
     launch_profiled(kern, dim3((unsigned)(p.nzc * p.nsy * p.nsx), (unsigned)(p.B * p.ncc)), dim3(p.NW * 64), lds, s, d, out, p);
     return hipGetLastError();
 }
 
+// lane_range false - sub-tiles inside one reference block on a grid of whole 16-byte quads per row, the usual case - takes
+// voxelize_pair_kernel (mvx_pair.hip); this kernel serves the per-lane-range cases (blockdim 4, 5, 12, ...) and the grids
+// written run by run (odd dimensions, unaligned slices), for which the caller also passes lane_range = true.
 hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, bool lane_range,
                                   hipStream_t s) {
     if (p.NW > 8) return hipErrorInvalidConfiguration;
-#define MVX_CASE(CT_)                                                                                                         \
-    if (ct == CT_) {                                                                                                          \
-        if (gauss) return lane_range ? launch_direct<CT_, true, true>(d, p, out, s) : launch_direct<CT_, true, false>(d, p, out, s);  \
-        return lane_range ? launch_direct<CT_, false, true>(d, p, out, s) : launch_direct<CT_, false, false>(d, p, out, s);         \
-    }
+    if (!lane_range) return launch_voxelize_pair(d, p, out, ct, gauss, s);
+#define MVX_CASE(CT_) \
+    if (ct == CT_) return gauss ? launch_direct<CT_, true>(d, p, out, s) : launch_direct<CT_, false>(d, p, out, s);
     MVX_CASE(1)
     MVX_CASE(4)
     MVX_CASE(8)

@@ -1,0 +1,466 @@
+// mvx_pair.hip - voxelize_pair_kernel: a whole per-molecule forward() call in ONE launch, two slabs per workgroup (gfx950).
+//
+// The reference's unit of work is one molecule per forward() call (test/test_time_numpy.py:11-15; Voxelizer.forward_features /
+// forward_types / forward_single, numpy/voxelizer.py:97-169, 240-315, 370-436). Such a call is a chain of latencies, not
+// work: launch -> coordinates -> which atoms reach this slab -> their records and weights -> walk -> stores. This kernel
+// replaces voxelize_direct_kernel (mvx_direct.hip, kept for the per-lane-range / run-wise variants) on that path. What
+// its phase timeline showed (tools/direct_timeline.py, cfg-2: scan 12.0 of a workgroup's 25.6 kcycles, 21 of 27 on the
+// reference's own timing loop) and what is different here:
+//   * the scan was vector-ALU work, ~90 instructions per 64 atoms (64-bit address clamps per load, spilled scalars read back
+//     lane by lane, scratch traffic inside the loop). Here: every load of a wave's share is issued up front as 16-byte
+//     loads with 32-bit offsets from one scalar base (3 per 128 atoms), and the test is ~30 instructions per 64 atoms;
+//   * every workgroup tested every atom. Here a workgroup owns TWO slabs side by side along x (4 x 4 x 8 NW voxels, 2 NW
+//     waves = up to 1024 threads, one workgroup per compute unit): one scan, one staged set of rows for both;
+//   * records were prepared by 8 lanes per wave from a merged list that every lane searched. Here the wave that found a
+//     candidate prepares it, one lane per candidate (its region of the list, its prefix): rows land in atom order without a
+//     lookup, and the exact float64 preparation runs once per wave instead of once per slot group;
+//   * the walk is the batched kernels' (OpsMx32 on the matrix cores for 32-channel chunks, OpsPair below that), so the
+//     sums are the same float32 chains in atom order: bit-identical to every other route.
+// Exactness is unchanged: the float32 scan only decides which atoms are LOOKED AT (a superset, error-bounded); box cull,
+// block culls, threshold and coefficient are decided in float64 with the reference's comparisons (stage), membership per
+// voxel by d2 <= T (walk).
+// LDS map (dynamic): u16 list[2 NW][512] | int wcnt[32] | union { strips 2 NW x 1.5 KB ; rows 128 x SW words ; 2 tiles }.
+#include "mvx_device.h"
+#include "mvx_ops32.h"
+
+#include <algorithm>
+
+namespace mvx {
+
+constexpr int PAIR_BLOCK = 128;                           // atoms per transposition block (3 x 1 KB of coordinates)
+constexpr int PAIR_MAX_BLOCKS = 4;                        // blocks a wave scans per segment (all loads in flight: 48 registers)
+constexpr int PAIR_SEGW = PAIR_BLOCK * PAIR_MAX_BLOCKS;   // atoms per wave and segment
+constexpr int PAIR_ROWS = 128;                            // candidate rows staged per round (both slabs share them)
+
+template <int CT, bool GAUSS>
+struct PairOps {
+    typedef OpsPair<CT, GAUSS> type;
+};
+template <bool GAUSS>
+struct PairOps<32, GAUSS> {
+    typedef OpsMx32<GAUSS, false, false, false> type;
+};
+
+__host__ __device__ inline int pair_tile_words(int ct, int NW) { // one slab's write-out tile (Ops::write)
+    const int cr = ct == 32 ? MX_CR : (ct < CR_F32 ? ct : CR_F32);
+    return cr * RPC * row_stride_floats(NW);
+}
+static size_t pair_lds_bytes(int32_t ct, int32_t NW) {
+    const size_t strips = (size_t)2 * NW * PAIR_BLOCK * 12;
+    const size_t rows = (size_t)PAIR_ROWS * cand_stride_words(ct) * 4;
+    const size_t tiles = (size_t)2 * pair_tile_words(ct, NW) * 4;
+    const size_t un = std::max(strips, std::max(rows, tiles));
+    return (size_t)2 * NW * PAIR_SEGW * 2 + 128 + un;
+}
+
+typedef unsigned u4a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef float f4a16 __attribute__((ext_vector_type(4)));
+
+template <int CT, bool GAUSS, bool XF>
+__global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A, float *__restrict__ out, const VoxParams P) {
+    typedef typename PairOps<CT, GAUSS>::type Ops;
+    constexpr int SW = Ops::SW;
+    constexpr int WW = Ops::WW; // weight words per row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = P.NW, NWT = 2 * NW;
+    const int h = wave >= NW ? 1 : 0; // which slab of the pair
+    const int ws = wave - h * NW;     // this wave's sub-tile along z
+    unsigned short *list = reinterpret_cast<unsigned short *>(smem);
+    int *wcnt = reinterpret_cast<int *>(smem + (size_t)NWT * PAIR_SEGW * 2);
+    unsigned *un = reinterpret_cast<unsigned *>(wcnt + 32);
+    unsigned short *region = list + wave * PAIR_SEGW; // this wave's survivors, in atom order
+
+    int b = (int)blockIdx.y, cc = 0;
+    if (P.ncc > 1) {
+        b = (int)blockIdx.y / P.ncc;
+        cc = (int)blockIdx.y - b * P.ncc;
+    }
+    int px, sy, zc;
+    decode_slab(blockIdx.x, P, px, sy, zc); // (nzc == 1: pair id = sy + nsy * px)
+    const int x0p = 2 * SUBX * px, x0 = x0p + SUBX * h, y0 = SUBY * sy, z0 = 0;
+    const int cbase = cc * CT;
+    const PrepArgs &pa = A.pa;
+    const int C = pa.C;
+    const Geom &g = pa.g;
+
+    int64_t a0 = 0, a1 = A.N;
+    if (pa.offsets) {
+        a0 = pa.offsets[b];
+        a1 = pa.offsets[b + 1];
+    }
+    const int N = (int)(a1 - a0);
+    mvx_xform xf;
+    if constexpr (XF) {
+        xf = pa.xf_one;
+        if (pa.xforms) xf = pa.xforms[b];
+    }
+#ifdef MVX_DIAG // per-workgroup s_memtime stamps into the (otherwise unused) record buffer: diagnostic builds only
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(pa.rec) + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+#define MVX_STAMP(i) do { if (tid == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    if (tid == 0) for (int i = 0; i < 8; ++i) stamps[i] = 0;
+#else
+#define MVX_STAMP(i) do { } while (0)
+#endif
+    MVX_STAMP(0);
+
+    // the pair's box (voxel centres), widened per atom by its radius window: a superset of the atoms that can reach it
+    const int D = P.D;
+    const int xh = (x0p + 2 * SUBX - 1 < D - 1) ? x0p + 2 * SUBX - 1 : D - 1;
+    const int yh = (y0 + SUBY - 1 < D - 1) ? y0 + SUBY - 1 : D - 1;
+    const double slack = 1e-6 * P.res;
+    const double bx0 = uniform((double)x0p * P.res - P.half - slack), bx1 = uniform((double)xh * P.res - P.half + slack);
+    const double by0 = uniform((double)y0 * P.res - P.half - slack), by1 = uniform((double)yh * P.res - P.half + slack);
+    const double bz0 = uniform(-P.half - slack), bz1 = uniform((double)(D - 1) * P.res - P.half + slack);
+
+    const bool small = N <= 2 * 64; // ligands: no scan - waves 0 and 1 stage every atom, the stage's own tests drop the far ones
+    const int SEGN = NWT * PAIR_SEGW;
+
+    // ---- A. scan of the segment that starts at atom s0 of the molecule: this wave's survivors -> region[0 .. cnt) ------------
+    auto scan = [&](int s0) -> int {
+        if (small) return wave < 2 ? ((N - 64 * wave) < 0 ? 0 : ((N - 64 * wave) > 64 ? 64 : N - 64 * wave)) : 0;
+        const int nseg = (N - s0) < SEGN ? (N - s0) : SEGN; // atoms of this segment
+        const int bpw = (nseg + PAIR_BLOCK * NWT - 1) / (PAIR_BLOCK * NWT); // blocks per wave, 1 ... PAIR_MAX_BLOCKS
+        const int wbeg = wave * bpw * PAIR_BLOCK; // first atom of this wave's share, relative to the segment
+        int cnt = 0;
+        if (wbeg >= nseg) return 0;
+        // float32 estimate of the transform and of the box (centre minus the transform's final offset, half extents rounded
+        // outwards): see make_xform_f32 / SCAN_MARGIN in mvx_device.h for the error bound
+        XformF32 X;
+        float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+        if constexpr (XF) {
+            X = make_xform_f32(xf);
+            o0 = X.o0;
+            o1 = X.o1;
+            o2 = X.o2;
+        }
+        const float ccx = uniform((float)(0.5 * (bx0 + bx1)) - o0), ccy = uniform((float)(0.5 * (by0 + by1)) - o1),
+                    ccz = uniform((float)(0.5 * (bz0 + bz1)) - o2);
+        const float hx = uniform((float)(0.5 * (bx1 - bx0)) * 1.000001f + 1e-6f), hy = uniform((float)(0.5 * (by1 - by0)) * 1.000001f + 1e-6f),
+                    hz = uniform((float)(0.5 * (bz1 - bz0)) * 1.000001f + 1e-6f);
+        // radius window of the scan: the scalar radius; per-type radii: the largest usable one of the table (the exact
+        // radius is the stage's business); atom-wise radii: fetched with the coordinates
+        const bool per_atom = pa.radii_src == RAD_ATOM;
+        float rwin_u = 0.0f;
+        if (pa.radii_src == RAD_SCALAR) rwin_u = (float)pa.radius_scalar;
+        else if (pa.radii_src == RAD_CHANNEL_BY_TYPE) {
+            float m = 0.0f;
+            for (int c = lane; c < C; c += 64) {
+                const float r = static_cast<const float *>(pa.radii)[c];
+                if (r > m && r < 3.0e38f) m = r;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            rwin_u = uniform(m);
+        }
+        // every load of this wave's share is issued before the first is used: lane l holds bytes [16 l, 16 l + 16) of
+        // each 1-KB third of a 128-atom block (clamped at the molecule's last 16 bytes: atoms past the end are masked)
+        const char *cb = reinterpret_cast<const char *>(pa.coords + 3 * (a0 + s0));
+        const unsigned lim = 24u * (unsigned)(N - s0) - 16u;
+        u4a8 fd[PAIR_MAX_BLOCKS][3];
+        float fr[PAIR_MAX_BLOCKS][2];
+#pragma unroll
+        for (int blk = 0; blk < PAIR_MAX_BLOCKS; ++blk) {
+            if (blk < bpw) {
+                const unsigned ob = 24u * (unsigned)(wbeg + blk * PAIR_BLOCK) + 16u * (unsigned)lane;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const unsigned o = ob + 1024u * k;
+                    u4a8 v = *reinterpret_cast<const u4a8 *>(cb + (o < lim ? o : lim));
+                    // an odd atom count ends in the middle of a 16-byte chunk: that chunk is fetched 8 bytes early (never a
+                    // byte past the molecule), so the last coordinate arrives in the upper half
+                    if (o == lim + 8u) {
+                        v.x = v.z;
+                        v.y = v.w;
+                    }
+                    fd[blk][k] = v;
+                }
+                if (per_atom) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int a = wbeg + blk * PAIR_BLOCK + 64 * q + lane;
+                        fr[blk][q] = static_cast<const float *>(pa.radii)[a0 + s0 + (a < nseg ? a : nseg - 1)];
+                    }
+                }
+            }
+        }
+        float *strip = reinterpret_cast<float *>(un) + (size_t)wave * PAIR_BLOCK * 3; // this wave's transposition strip
+#pragma unroll
+        for (int blk = 0; blk < PAIR_MAX_BLOCKS; ++blk) {
+            if (blk < bpw) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double d0 = __hiloint2double((int)fd[blk][k].y, (int)fd[blk][k].x);
+                    const double d1 = __hiloint2double((int)fd[blk][k].w, (int)fd[blk][k].z);
+                    *reinterpret_cast<float2v *>(strip + 128 * k + 2 * lane) = (float2v){(float)d0, (float)d1};
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = 64 * q + lane;
+                    const int a = wbeg + blk * PAIR_BLOCK + j;
+                    float x = strip[3 * j], y = strip[3 * j + 1], z = strip[3 * j + 2];
+                    const float rwin = per_atom ? fr[blk][q] : rwin_u;
+                    float mag = fabsf(x) + fabsf(y) + fabsf(z);
+                    if constexpr (XF) {
+                        mag = X.scale * mag + X.mag;
+                        x -= X.c0;
+                        y -= X.c1;
+                        z -= X.c2;
+                        if (X.rot) {
+                            const float u = X.m00 * x + X.m01 * y + X.m02 * z;
+                            const float v = X.m10 * x + X.m11 * y + X.m12 * z;
+                            const float w = X.m20 * x + X.m21 * y + X.m22 * z;
+                            x = u;
+                            y = v;
+                            z = w;
+                        }
+                    } else {
+                        mag += 1.0f;
+                    }
+                    // every test widened by the estimate's error bound; magnitudes float32 cannot hold are left to float64
+                    const float rr = rwin * 1.00001f + SCAN_MARGIN * mag + 1e-6f;
+                    const bool near = (fabsf(x - ccx) <= hx + rr) & (fabsf(y - ccy) <= hy + rr) & (fabsf(z - ccz) <= hz + rr);
+                    const bool ok = (a < nseg) & (near | !(mag < 1.0e30f));
+                    const unsigned long long mk = __ballot(ok);
+                    if (ok) region[cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u))] = (unsigned short)a;
+                    cnt += __popcll(mk);
+                }
+            }
+        }
+        return cnt;
+    };
+
+    // ---- B. stage: this wave prepares ITS survivors [lo, hi) of segment s0, one lane each, into rows rowbase + i ------------
+    const BlockBounds Bx = block_bounds(g, x0p), By = block_bounds(g, y0); // the reference blocks this pair lies in
+    auto stage = [&](int s0, int lo, int hi, int rowbase) {
+        for (int i0 = lo; i0 < hi; i0 += 64) { // (one trip unless a wave found more than 64 candidates)
+            const int i = i0 + lane;
+            const bool valid = i < hi;
+            int idx = 0;
+            if (valid) idx = small ? 64 * wave + i : (int)region[i];
+            const unsigned arel = (unsigned)(s0 + idx); // atom index inside the molecule
+            unsigned *row = un + (size_t)(rowbase + i) * SW;
+            if (valid) {
+                const double *cp = pa.coords + 3 * a0;
+                double p[3] = {cp[3u * arel], cp[3u * arel + 1u], cp[3u * arel + 2u]};
+                int my_type = 0;
+                bool keep = true;
+                if (pa.types) {
+                    my_type = (pa.types + a0)[arel];
+                    if (my_type < 0 || my_type >= C) keep = false;
+                }
+                float r32;
+                double rc;
+                if (pa.radii_src == RAD_SCALAR) {
+                    rc = pa.radius_scalar;
+                    r32 = (float)pa.radius_scalar;
+                } else {
+                    const int64_t ri = (pa.radii_src == RAD_ATOM) ? a0 + (int64_t)arel : (keep ? (int64_t)my_type : -1); // numpy/voxelizer.py:284-285
+                    r32 = ri >= 0 ? static_cast<const float *>(pa.radii)[ri] : 0.0f;
+                    rc = (double)r32;
+                }
+                // features whose rows are whole 16-byte quads: this lane fetches its own row (CT / 4 loads in flight)
+                f4a16 wq[CT >= 4 ? CT / 4 : 1];
+                const bool own_row = pa.mode == MODE_FEATURES && CT >= 4 && (C & 3) == 0 && cbase + CT <= C &&
+                                     (reinterpret_cast<uintptr_t>(pa.features) & 15u) == 0;
+                if (own_row) {
+                    const f4a16 *fp = reinterpret_cast<const f4a16 *>(static_cast<const float *>(pa.features) + (a0 + arel) * C + cbase);
+#pragma unroll
+                    for (int qd = 0; qd < CT / 4; ++qd) wq[qd] = fp[qd];
+                }
+#ifdef MVX_DIAG
+                if (p[0] != 1.2345e300) MVX_STAMP(7); // (after the coordinates have arrived)
+#endif
+                if constexpr (XF) apply_xform(xf, p[0], p[1], p[2]);
+                const double ub = g.half, lb = -1 * g.half;
+                if (pa.radii_src == RAD_SCALAR) {
+                    for (int q = 0; q < 3; ++q) keep = keep && (p[q] > lb - rc) && (p[q] < ub + rc); // numpy/voxelizer.py:487-488
+                } else {
+                    for (int q = 0; q < 3; ++q) keep = keep && (p[q] + rc > lb) && (p[q] - rc < ub); // :491-492
+                }
+                // (one python float for every atom: threshold and coefficient come with the launch)
+                const double T = pa.radii_src == RAD_SCALAR ? pa.T_scalar : d2_threshold(r32);
+                keep = keep && (T >= 0.0);
+                // sub-tiles lie inside one reference block: the x / y block culls are uniform over the pair (its 4 x 4 voxels
+                // share a block: blockdim is a multiple of 8 here), the z cull over each wave's sub-tile (walk)
+                keep = keep && block_admits(Bx, p[0], rc) && block_admits(By, p[1], rc);
+                const double rrd = (double)r32 * 1.000001 + 1e-9; // conservative window, as prep_atom's
+                keep = keep && (p[0] + rrd >= bx0) && (p[0] - rrd <= bx1) && (p[1] + rrd >= by0) && (p[1] - rrd <= by1) &&
+                       (p[2] + rrd >= bz0) && (p[2] - rrd <= bz1);
+                typedef double d2v __attribute__((ext_vector_type(2)));
+                d2v *dst = reinterpret_cast<d2v *>(row);
+                dst[0] = (d2v){p[0], p[1]};
+                dst[1] = (d2v){p[2], T};
+                row[8] = __float_as_uint(!GAUSS ? 0.0f : (pa.radii_src == RAD_SCALAR ? pa.k_scalar : gauss_coeff(r32, pa.sigma32)));
+                row[9] = (unsigned)my_type;
+                *reinterpret_cast<double *>(row + 10) = rc;
+                // window radius, rounded up to float; a dropped candidate gets a negative one
+                row[12] = __float_as_uint(keep ? (float)rrd * 1.0000002f : -1.0f);
+                if (own_row) {
+#pragma unroll
+                    for (int qd = 0; qd < CT / 4; ++qd) *reinterpret_cast<f4a16 *>(row + 16 + 4 * qd) = wq[qd];
+                } else if (pa.mode != MODE_FEATURES) { // one-hot type row / the unit weight of forward_single
+#pragma unroll
+                    for (int j = 0; j < WW; ++j) {
+                        const bool one = pa.mode == MODE_TYPES ? (my_type == cbase + j) : (j == 0);
+                        row[16 + j] = one ? 0x3f800000u : 0u;
+                    }
+                }
+            }
+            if (pa.mode == MODE_FEATURES) { // (uniform) any other feature layout: 64 / WW rows per load, one word per lane
+                const bool own_row = CT >= 4 && (C & 3) == 0 && cbase + CT <= C && (reinterpret_cast<uintptr_t>(pa.features) & 15u) == 0;
+                if (!own_row) {
+                    constexpr int RPI = 64 / WW;
+                    const int n = (hi - i0) < 64 ? (hi - i0) : 64;
+                    const float *feat = static_cast<const float *>(pa.features) + a0 * C;
+                    for (int r0 = 0; r0 < n; r0 += RPI) {
+                        const int rr_ = r0 + lane / WW, j = lane % WW;
+                        if (rr_ < n) {
+                            const unsigned ar = (unsigned)(s0 + (small ? 64 * wave + i0 + rr_ : (int)region[i0 + rr_]));
+                            float v = 0.0f;
+                            if (cbase + j < C) v = feat[(size_t)ar * C + cbase + j];
+                            un[(size_t)(rowbase + i0 + rr_) * SW + 16 + j] = __float_as_uint(v);
+                        }
+                    }
+                }
+            }
+        }
+        MVX_STAMP(2);
+    };
+
+    // this wave's survivors and where they fall in the segment's candidate order
+    auto prefix = [&](int cnt, int &pre_mine) -> int {
+        if (lane == 0) wcnt[wave] = cnt;
+        __syncthreads();
+        const int c = lane < NWT ? wcnt[lane] : 0;
+        int total = 0;
+        pre_mine = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int cw = __builtin_amdgcn_readlane(c, w);
+            pre_mine += w < wave ? cw : 0;
+            total += cw;
+        }
+        MVX_STAMP(1);
+        return total;
+    };
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+
+    // The first round of the first segment is staged BEFORE the accumulators exist: scan and stage have the whole register
+    // file, and per-molecule calls rarely need more than this one round per pair.
+    int cnt0 = 0, pre0 = 0, total0 = 0;
+    if (N > 0) {
+        cnt0 = scan(0);
+        total0 = prefix(cnt0, pre0);
+        if (total0 > 0) {
+            stage(0, clampi(0 - pre0, 0, cnt0), clampi(PAIR_ROWS - pre0, 0, cnt0), pre0);
+            __syncthreads();
+            MVX_STAMP(3);
+        }
+    }
+
+    // (voxel centres and accumulators only from here on)
+    LaneCtx L = Ops::ctx(lane, ws, x0, y0, z0, 0, cbase, P);
+    typename Ops::Acc acc;
+    Ops::zero(acc);
+    bool any = false;
+    // per-wave constants of the row filter: this sub-tile's z block and z window, this slab's x window
+    const int zv = z0 + SUBZ * ws;
+    const int zl = (zv + SUBZ - 1 < D - 1) ? zv + SUBZ - 1 : D - 1;
+    const int xl = (x0 + SUBX - 1 < D - 1) ? x0 + SUBX - 1 : D - 1;
+    const BlockBounds Bz = block_bounds(g, zv);
+    const double wz0 = uniform((double)zv * P.res - P.half - slack), wz1 = uniform((double)zl * P.res - P.half + slack);
+    const double wx0 = uniform((double)x0 * P.res - P.half - slack), wx1 = uniform((double)xl * P.res - P.half + slack);
+    // ---- C. the rows this wave's sub-tile takes (one lane per row), then the walk ----------------------------------------
+    auto walk = [&](int n) {
+#pragma unroll
+        for (int half = 0; half < PAIR_ROWS / 64; ++half) {
+            if (64 * half < n) {
+                bool ok = false, kept = false;
+                const int rw = 64 * half + lane;
+                if (rw < n) {
+                    const unsigned *r = un + (size_t)rw * SW;
+                    const double pxr = *reinterpret_cast<const double *>(r);
+                    const double pz = *reinterpret_cast<const double *>(r + 4);
+                    const double rc = *reinterpret_cast<const double *>(r + 10);
+                    const double rr = (double)__uint_as_float(r[12]);
+                    kept = rr >= 0.0;
+                    ok = kept && (zv < D) && block_admits(Bz, pz, rc) && (pz + rr >= wz0) && (pz - rr <= wz1) && (pxr + rr >= wx0) &&
+                         (pxr - rr <= wx1);
+                }
+                any = any || __ballot(kept) != 0ull; // (the same rows in every wave: workgroup-uniform)
+                Ops::walk(acc, __ballot(ok), un + (size_t)64 * half * SW, lane, L, P, nullptr, nullptr);
+            }
+        }
+        MVX_STAMP(4);
+    };
+    if (total0 > 0) {
+        walk(total0 < PAIR_ROWS ? total0 : PAIR_ROWS);
+#pragma nounroll
+        for (int r0 = PAIR_ROWS; r0 < total0; r0 += PAIR_ROWS) {
+            __syncthreads(); // every wave is done with the previous round's rows
+            stage(0, clampi(r0 - pre0, 0, cnt0), clampi(r0 + PAIR_ROWS - pre0, 0, cnt0), pre0 - r0);
+            __syncthreads();
+            walk((total0 - r0) < PAIR_ROWS ? (total0 - r0) : PAIR_ROWS);
+        }
+    }
+#pragma nounroll
+    for (int s0 = SEGN; s0 < N; s0 += SEGN) { // molecules of more than 512 atoms per wave: further segments
+        __syncthreads(); // rows consumed before the scan strips overwrite them
+        const int cnt = scan(s0);
+        int pre;
+        const int total = prefix(cnt, pre);
+#pragma nounroll
+        for (int r0 = 0; r0 < total; r0 += PAIR_ROWS) {
+            __syncthreads(); // (strips / previous rows consumed)
+            stage(s0, clampi(r0 - pre, 0, cnt), clampi(r0 + PAIR_ROWS - pre, 0, cnt), pre - r0);
+            __syncthreads();
+            walk((total - r0) < PAIR_ROWS ? (total - r0) : PAIR_ROWS);
+        }
+    }
+    MVX_STAMP(5);
+    // write-out of this wave's slab (each half has its own tile; `any` is uniform over the pair, so both halves pass the
+    // same barriers); begins with a barrier
+    unsigned *tile = un + (size_t)h * pair_tile_words(CT, NW);
+    Ops::write(acc, any ? 1 : 0, tile, tid - h * NW * 64, lane, ws, NW, b, L, x0, y0, z0, out, P);
+    MVX_STAMP(6);
+#undef MVX_STAMP
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch
+// ------------------------------------------------------------------------------------------------
+template <int CT, bool GAUSS, bool XF>
+static hipError_t launch_pair_t(const DirectArgs &d, const VoxParams &p, float *out, hipStream_t s) {
+    static LdsLimit raised;
+    const size_t lds = pair_lds_bytes(CT, p.NW);
+    auto kern = &voxelize_pair_kernel<CT, GAUSS, XF>;
+    hipError_t e = raise_lds_limit(kern, lds, raised);
+    if (e != hipSuccess) return e;
+    launch_profiled(kern, dim3((unsigned)(p.nsy * (p.nsx / 2)), (unsigned)(p.B * p.ncc)), dim3(p.NW * 128), lds, s, d, out, p);
+    return hipGetLastError();
+}
+
+// aligned float32 grids (rows of whole 16-byte quads: D % 4 == 0, so the x-slabs pair up), sub-tiles inside one reference
+// block, whole rows per slab (NW <= 8)
+hipError_t launch_voxelize_pair(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, hipStream_t s) {
+    if (p.B <= 0) return hipSuccess;
+    if (p.NW > 8 || p.nzc != 1 || !p.vec_store || (p.nsx & 1) || (long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
+    const bool xf = d.pa.xforms != nullptr || d.pa.xf_one.flags != 0;
+#define MVX_CASE(CT_)                                                                                                       \
+    if (ct == CT_) {                                                                                                        \
+        if (gauss) return xf ? launch_pair_t<CT_, true, true>(d, p, out, s) : launch_pair_t<CT_, true, false>(d, p, out, s);   \
+        return xf ? launch_pair_t<CT_, false, true>(d, p, out, s) : launch_pair_t<CT_, false, false>(d, p, out, s);           \
+    }
+    MVX_CASE(1)
+    MVX_CASE(4)
+    MVX_CASE(8)
+    MVX_CASE(16)
+    MVX_CASE(32)
+#undef MVX_CASE
+    return hipErrorInvalidValue;
+}
+
+} // namespace mvx

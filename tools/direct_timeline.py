@@ -1,4 +1,4 @@
-"""Per-phase timeline of voxelize_direct_kernel from a -DMVX_DIAG build (tools/ab_build.sh diag "-DMVX_DIAG").
+"""Per-phase timeline of voxelize_pair_kernel (the per-molecule launch) from a -DMVX_DIAG build (tools/ab_build.sh diag "-DMVX_DIAG").
 
     python3 tools/direct_timeline.py cfg1|cfg2|harness [lib]
 Stamps (s_memtime, 100 MHz constant clock -> 10 ns ticks... printed in us) per workgroup:
@@ -41,7 +41,7 @@ grid = vox.get_empty_grid(C_)
 for _ in range(20):
     vox.forward(coords, cen, chan, radii, tr, rot, out_grid=grid)
 torch.cuda.synchronize()
-nwg = ((D + 1) // 2) * ((D + 3) // 4) * max(1, (D + 63) // 64)
+nwg = ((D + 3) // 4) * ((D + 3) // 4)  # voxelize_pair_kernel: one workgroup per pair of x-slabs (D % 4 == 0)
 buf = np.zeros((nwg, 8), dtype=np.uint64)
 _l.check(vox._lib.mvx_debug_read_records(vox._handle, buf.ctypes.data, nwg, 0))
 t = buf.astype(np.float64)
