@@ -161,7 +161,7 @@ void make_geom(mvx_handle *h) {
     g.D = c.dimension;
     g.bd = c.blockdim > 0 ? c.blockdim : 8;                        // numpy/voxelizer.py:38
     g.nb = (g.D + g.bd - 1) / g.bd;                                // numpy/voxelizer.py:44
-    g.pad = 0;
+    g.bd_inv = g.bd > 1 ? (uint32_t)((0x100000000ull + (uint64_t)g.bd - 1) / (uint64_t)g.bd) : 0u;
     g.inv_res = 1.0 / g.res;
     g.inv_pitch = 1.0 / ((double)g.bd * g.res);
     h->g = g;
@@ -552,6 +552,7 @@ int run(mvx_handle *h, const RunArgs &r) {
 #ifdef MVX_DIAG // stamps of every workgroup (8 x 8 B each), read back with mvx_debug_read_records
         if ((rc = ensure(w.rec, nslabs * (size_t)ncc * 64))) return rc;
         da.pa.rec = reinterpret_cast<AtomRec *>(w.rec.p);
+        HIP_TRY(hipMemsetAsync(w.rec.p, 0, nslabs * (size_t)ncc * 64, s)); // (slots filled by atomicMax need a zero start)
 #endif
         da.pa.wbuf = nullptr;
         da.pa.xp = nullptr;

@@ -392,6 +392,19 @@ __device__ __forceinline__ BlockBounds block_bounds(const Geom &g, int v) {
     B.hi = uniform(((double)((blk + 1) * g.bd) * g.res - g.half) + hres); // bounds[blk]
     return B;
 }
+// the same without the integer division and without moving anything to scalar registers (voxelize_pair_kernel: evaluated
+// once, by the few lanes that prepare records)
+__device__ __forceinline__ BlockBounds block_bounds_lane(const Geom &g, int v) {
+    BlockBounds B;
+    int blk = g.bd > 1 ? (int)__umulhi((unsigned)v, g.bd_inv) : v;
+    if (blk > g.nb - 1) blk = g.nb - 1;
+    const double hres = g.res / 2.0;
+    B.has_lo = g.nb > 1 && blk >= 1;
+    B.has_hi = g.nb > 1 && blk <= g.nb - 2;
+    B.lo = ((double)(blk * g.bd) * g.res - g.half) + hres;       // bounds[blk - 1]
+    B.hi = ((double)((blk + 1) * g.bd) * g.res - g.half) + hres; // bounds[blk]
+    return B;
+}
 __device__ __forceinline__ bool block_admits(const BlockBounds &B, double p, double r) {
     return (!B.has_lo || p > B.lo - r) && (!B.has_hi || p < B.hi + r);
 }

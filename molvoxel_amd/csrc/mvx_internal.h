@@ -40,7 +40,7 @@ struct Geom {
     int32_t D;
     int32_t bd;  // reference blockdim (cull emulation)
     int32_t nb;  // ceil(D / bd)
-    int32_t pad;
+    uint32_t bd_inv; // ceil(2^32 / bd): v / bd == __umulhi(v, bd_inv) for voxel indices (v * bd < 2^32; bd >= 2)
     double inv_res;   // 1.0 / res
     double inv_pitch; // 1.0 / (bd * res)
 };

@@ -19,7 +19,8 @@
 // Exactness is unchanged: the float32 scan only decides which atoms are LOOKED AT (a superset, error-bounded); box cull,
 // block culls, threshold and coefficient are decided in float64 with the reference's comparisons (stage), membership per
 // voxel by d2 <= T (walk).
-// LDS map (dynamic): u16 list[2 NW][512] | int wcnt[32] | union { strips 2 NW x 1.5 KB ; rows 128 x SW words ; 2 tiles }.
+// LDS map (dynamic): u16 list[2 NW][512] | PairStash stash[2 NW][48] | int wcnt[32] | float rtab[256] |
+//                    union { float64 strips 2 NW x 3 KB ; rows 128 x SW words ; 2 tiles }.
 #include "mvx_device.h"
 #include "mvx_ops32.h"
 
@@ -31,6 +32,14 @@ constexpr int PAIR_BLOCK = 128;                           // atoms per transposi
 constexpr int PAIR_MAX_BLOCKS = 4;                        // blocks a wave scans per segment (all loads in flight: 48 registers)
 constexpr int PAIR_SEGW = PAIR_BLOCK * PAIR_MAX_BLOCKS;   // atoms per wave and segment
 constexpr int PAIR_ROWS = 128;                            // candidate rows staged per round (both slabs share them)
+constexpr int PAIR_STASH = 48;                            // survivors per wave and segment whose float64 position, radius and type stay in LDS
+constexpr int PAIR_RTAB = 256;                            // per-type radii kept in LDS (forward_types with channel-wise radii)
+struct __attribute__((aligned(16))) PairStash {           // what the scan already held about a survivor: no second trip to memory
+    double x, y, z;
+    float r;      // atom-wise radius
+    int32_t type; // forward_types channel
+};
+static_assert(sizeof(PairStash) == 32, "two 16-byte LDS writes per survivor");
 
 template <int CT, bool GAUSS>
 struct PairOps {
@@ -46,15 +55,24 @@ __host__ __device__ inline int pair_tile_words(int ct, int NW) { // one slab's w
     return cr * RPC * row_stride_floats(NW);
 }
 static size_t pair_lds_bytes(int32_t ct, int32_t NW) {
-    const size_t strips = (size_t)2 * NW * PAIR_BLOCK * 12;
+    const size_t strips = (size_t)2 * NW * PAIR_BLOCK * 24;
     const size_t rows = (size_t)PAIR_ROWS * cand_stride_words(ct) * 4;
     const size_t tiles = (size_t)2 * pair_tile_words(ct, NW) * 4;
     const size_t un = std::max(strips, std::max(rows, tiles));
-    return (size_t)2 * NW * PAIR_SEGW * 2 + 128 + un;
+    return (size_t)2 * NW * (PAIR_SEGW * 2 + PAIR_STASH * sizeof(PairStash)) + 128 + PAIR_RTAB * 4 + un;
 }
 
 typedef unsigned u4a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef float f4a16 __attribute__((ext_vector_type(4)));
+
+// inclusive prefix over the 16 lanes of a row (row_shr: lanes shifted in from outside the row read 0)
+__device__ __forceinline__ int row_prefix16(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    return v;
+}
 
 template <int CT, bool GAUSS, bool XF>
 __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A, float *__restrict__ out, const VoxParams P) {
@@ -69,9 +87,12 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
     const int h = wave >= NW ? 1 : 0; // which slab of the pair
     const int ws = wave - h * NW;     // this wave's sub-tile along z
     unsigned short *list = reinterpret_cast<unsigned short *>(smem);
-    int *wcnt = reinterpret_cast<int *>(smem + (size_t)NWT * PAIR_SEGW * 2);
-    unsigned *un = reinterpret_cast<unsigned *>(wcnt + 32);
+    PairStash *stash_all = reinterpret_cast<PairStash *>(smem + (size_t)NWT * PAIR_SEGW * 2);
+    int *wcnt = reinterpret_cast<int *>(stash_all + (size_t)NWT * PAIR_STASH);
+    float *rtab = reinterpret_cast<float *>(wcnt + 32);
+    unsigned *un = reinterpret_cast<unsigned *>(rtab + PAIR_RTAB);
     unsigned short *region = list + wave * PAIR_SEGW; // this wave's survivors, in atom order
+    PairStash *stash = stash_all + wave * PAIR_STASH; // ... and what the scan knew about the first PAIR_STASH of them
 
     int b = (int)blockIdx.y, cc = 0;
     if (P.ncc > 1) {
@@ -85,6 +106,7 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
     const PrepArgs &pa = A.pa;
     const int C = pa.C;
     const Geom &g = pa.g;
+    const int D = P.D;
 
     int64_t a0 = 0, a1 = A.N;
     if (pa.offsets) {
@@ -98,71 +120,46 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
         if (pa.xforms) xf = pa.xforms[b];
     }
 #ifdef MVX_DIAG // per-workgroup s_memtime stamps into the (otherwise unused) record buffer: diagnostic builds only
-    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(pa.rec) + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    // (16 slots per workgroup = the 8 per slab the host allocates, zeroed before the launch; slots 11-13 take the LATEST wave's time)
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(pa.rec) + 16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
 #define MVX_STAMP(i) do { if (tid == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
-    if (tid == 0) for (int i = 0; i < 8; ++i) stamps[i] = 0;
+#define MVX_STAMP_MAX(i) do { if (lane == 0) atomicMax(&stamps[i], (unsigned long long)__builtin_amdgcn_s_memtime()); } while (0)
+    MVX_STAMP_MAX(13);
 #else
 #define MVX_STAMP(i) do { } while (0)
+#define MVX_STAMP_MAX(i) do { } while (0)
 #endif
     MVX_STAMP(0);
 
-    // the pair's box (voxel centres), widened per atom by its radius window: a superset of the atoms that can reach it
-    const int D = P.D;
-    const int xh = (x0p + 2 * SUBX - 1 < D - 1) ? x0p + 2 * SUBX - 1 : D - 1;
-    const int yh = (y0 + SUBY - 1 < D - 1) ? y0 + SUBY - 1 : D - 1;
-    const double slack = 1e-6 * P.res;
-    const double bx0 = uniform((double)x0p * P.res - P.half - slack), bx1 = uniform((double)xh * P.res - P.half + slack);
-    const double by0 = uniform((double)y0 * P.res - P.half - slack), by1 = uniform((double)yh * P.res - P.half + slack);
-    const double bz0 = uniform(-P.half - slack), bz1 = uniform((double)(D - 1) * P.res - P.half + slack);
-
-    const bool small = N <= 2 * 64; // ligands: no scan - waves 0 and 1 stage every atom, the stage's own tests drop the far ones
+    const bool small = N <= PAIR_ROWS; // ligands: no scan - every atom gets a row, the stage's own tests drop the far ones
     const int SEGN = NWT * PAIR_SEGW;
 
     // ---- A. scan of the segment that starts at atom s0 of the molecule: this wave's survivors -> region[0 .. cnt) ------------
-    auto scan = [&](int s0) -> int {
-        if (small) return wave < 2 ? ((N - 64 * wave) < 0 ? 0 : ((N - 64 * wave) > 64 ? 64 : N - 64 * wave)) : 0;
+    // (deliberately short: sixteen waves run it side by side, so every instruction here costs ~16 cycles of a call)
+    auto scan = [&](int s0) __attribute__((always_inline)) -> int {
+        MVX_STAMP(8);
         const int nseg = (N - s0) < SEGN ? (N - s0) : SEGN; // atoms of this segment
         const int bpw = (nseg + PAIR_BLOCK * NWT - 1) / (PAIR_BLOCK * NWT); // blocks per wave, 1 ... PAIR_MAX_BLOCKS
         const int wbeg = wave * bpw * PAIR_BLOCK; // first atom of this wave's share, relative to the segment
         int cnt = 0;
         if (wbeg >= nseg) return 0;
-        // float32 estimate of the transform and of the box (centre minus the transform's final offset, half extents rounded
-        // outwards): see make_xform_f32 / SCAN_MARGIN in mvx_device.h for the error bound
-        XformF32 X;
-        float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
-        if constexpr (XF) {
-            X = make_xform_f32(xf);
-            o0 = X.o0;
-            o1 = X.o1;
-            o2 = X.o2;
-        }
-        const float ccx = uniform((float)(0.5 * (bx0 + bx1)) - o0), ccy = uniform((float)(0.5 * (by0 + by1)) - o1),
-                    ccz = uniform((float)(0.5 * (bz0 + bz1)) - o2);
-        const float hx = uniform((float)(0.5 * (bx1 - bx0)) * 1.000001f + 1e-6f), hy = uniform((float)(0.5 * (by1 - by0)) * 1.000001f + 1e-6f),
-                    hz = uniform((float)(0.5 * (bz1 - bz0)) * 1.000001f + 1e-6f);
-        // radius window of the scan: the scalar radius; per-type radii: the largest usable one of the table (the exact
-        // radius is the stage's business); atom-wise radii: fetched with the coordinates
-        const bool per_atom = pa.radii_src == RAD_ATOM;
-        float rwin_u = 0.0f;
-        if (pa.radii_src == RAD_SCALAR) rwin_u = (float)pa.radius_scalar;
-        else if (pa.radii_src == RAD_CHANNEL_BY_TYPE) {
-            float m = 0.0f;
-            for (int c = lane; c < C; c += 64) {
-                const float r = static_cast<const float *>(pa.radii)[c];
-                if (r > m && r < 3.0e38f) m = r;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            rwin_u = uniform(m);
-        }
-        // every load of this wave's share is issued before the first is used: lane l holds bytes [16 l, 16 l + 16) of
-        // each 1-KB third of a 128-atom block (clamped at the molecule's last 16 bytes: atoms past the end are masked)
+        // every load of this wave's share is issued before anything else: lane l holds bytes [16 l, 16 l + 16) of each
+        // 1-KB third of a 128-atom block (clamped at the molecule's last 16 bytes: atoms past the end are masked), plus the
+        // atoms' radii / types where the call has them per atom
         const char *cb = reinterpret_cast<const char *>(pa.coords + 3 * (a0 + s0));
         const unsigned lim = 24u * (unsigned)(N - s0) - 16u;
+        const bool per_atom = pa.radii_src == RAD_ATOM;
+        const bool typed = pa.types != nullptr;
         u4a8 fd[PAIR_MAX_BLOCKS][3];
         float fr[PAIR_MAX_BLOCKS][2];
+        int ft[PAIR_MAX_BLOCKS][2];
 #pragma unroll
         for (int blk = 0; blk < PAIR_MAX_BLOCKS; ++blk) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                fr[blk][q] = 0.0f;
+                ft[blk][q] = 0;
+            }
             if (blk < bpw) {
                 const unsigned ob = 24u * (unsigned)(wbeg + blk * PAIR_BLOCK) + 16u * (unsigned)lane;
 #pragma unroll
@@ -177,34 +174,73 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
                     }
                     fd[blk][k] = v;
                 }
-                if (per_atom) {
+                if (per_atom | typed) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int a = wbeg + blk * PAIR_BLOCK + 64 * q + lane;
-                        fr[blk][q] = static_cast<const float *>(pa.radii)[a0 + s0 + (a < nseg ? a : nseg - 1)];
+                        const int64_t ag = a0 + s0 + (a < nseg ? a : nseg - 1);
+                        if (per_atom) fr[blk][q] = static_cast<const float *>(pa.radii)[ag];
+                        if (typed) ft[blk][q] = pa.types[ag];
                     }
                 }
             }
         }
-        float *strip = reinterpret_cast<float *>(un) + (size_t)wave * PAIR_BLOCK * 3; // this wave's transposition strip
+        MVX_STAMP(9);
+        // (under the loads) the pair's box as float32 centre and half extents: voxels x0p .. x0p + 3, y0 .. y0 + 3, whole
+        // rows (the pair lies inside the grid: D % 4 == 0), minus the transform's final offset; the half extents carry the
+        // rounding of this very estimate (a few 1e-7 of the magnitudes involved). The atom's side of the error bound is
+        // SCAN_MARGIN times its magnitude (make_xform_f32 in mvx_device.h); membership is never decided here.
+        const float resf = (float)P.res, halff = (float)P.half;
+        XformF32 X;
+        float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+        if constexpr (XF) {
+            X = make_xform_f32(xf);
+            o0 = X.o0;
+            o1 = X.o1;
+            o2 = X.o2;
+        }
+        const float eps = 4.0e-6f * (fabsf(halff) + resf * (float)D + fabsf(o0) + fabsf(o1) + fabsf(o2) + 1.0f);
+        const float ccx = ((float)x0p + 1.5f) * resf - halff - o0, ccy = ((float)y0 + 1.5f) * resf - halff - o1,
+                    ccz = 0.5f * (float)(D - 1) * resf - halff - o2;
+        const float hx = 1.5f * resf + eps, hy = hx, hz = 0.5f * (float)(D - 1) * resf + eps;
+        // radius window of the scan: the scalar radius; per-type radii: the largest usable one of the table (the exact
+        // radius is the stage's business); atom-wise radii: fetched with the coordinates
+        float rwin_u = 0.0f;
+        if (pa.radii_src == RAD_SCALAR) rwin_u = (float)pa.radius_scalar;
+        else if (pa.radii_src == RAD_CHANNEL_BY_TYPE) {
+            float m = 0.0f;
+            for (int c = lane; c < C; c += 64) {
+                const float r = static_cast<const float *>(pa.radii)[c];
+                if (r > m && r < 3.0e38f) m = r;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            rwin_u = m;
+        }
+        // rr = rwin * 1.00001 + SCAN_MARGIN * mag + 1e-6 with mag = scale * (|x| + |y| + |z|) + X.mag (1 without a transform)
+        float mscale = SCAN_MARGIN, mbase = SCAN_MARGIN + 1e-6f;
+        if constexpr (XF) {
+            mscale = SCAN_MARGIN * X.scale;
+            mbase = SCAN_MARGIN * X.mag + 1e-6f;
+        }
+        const float rbase_u = rwin_u * 1.00001f + mbase;
+        double *strip = reinterpret_cast<double *>(un) + (size_t)wave * PAIR_BLOCK * 3; // this wave's transposition strip
 #pragma unroll
         for (int blk = 0; blk < PAIR_MAX_BLOCKS; ++blk) {
             if (blk < bpw) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const double d0 = __hiloint2double((int)fd[blk][k].y, (int)fd[blk][k].x);
-                    const double d1 = __hiloint2double((int)fd[blk][k].w, (int)fd[blk][k].z);
-                    *reinterpret_cast<float2v *>(strip + 128 * k + 2 * lane) = (float2v){(float)d0, (float)d1};
-                }
+                for (int k = 0; k < 3; ++k)
+                    *reinterpret_cast<uint4 *>(strip + 128 * k + 2 * lane) = make_uint4(fd[blk][k].x, fd[blk][k].y, fd[blk][k].z, fd[blk][k].w);
+                if (blk == 0) MVX_STAMP(10);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int j = 64 * q + lane;
                     const int a = wbeg + blk * PAIR_BLOCK + j;
-                    float x = strip[3 * j], y = strip[3 * j + 1], z = strip[3 * j + 2];
-                    const float rwin = per_atom ? fr[blk][q] : rwin_u;
-                    float mag = fabsf(x) + fabsf(y) + fabsf(z);
+                    const double xd = strip[3 * j], yd = strip[3 * j + 1], zd = strip[3 * j + 2];
+                    float x = (float)xd, y = (float)yd, z = (float)zd;
+                    const float asum = fabsf(x) + fabsf(y) + fabsf(z);
+                    const float rr = mscale * asum + (per_atom ? fr[blk][q] * 1.00001f + mbase : rbase_u);
                     if constexpr (XF) {
-                        mag = X.scale * mag + X.mag;
                         x -= X.c0;
                         y -= X.c1;
                         z -= X.c2;
@@ -216,49 +252,97 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
                             y = v;
                             z = w;
                         }
-                    } else {
-                        mag += 1.0f;
                     }
                     // every test widened by the estimate's error bound; magnitudes float32 cannot hold are left to float64
-                    const float rr = rwin * 1.00001f + SCAN_MARGIN * mag + 1e-6f;
                     const bool near = (fabsf(x - ccx) <= hx + rr) & (fabsf(y - ccy) <= hy + rr) & (fabsf(z - ccz) <= hz + rr);
-                    const bool ok = (a < nseg) & (near | !(mag < 1.0e30f));
+                    const bool ok = (a < nseg) & (near | !(asum < 1.0e30f));
                     const unsigned long long mk = __ballot(ok);
-                    if (ok) region[cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u))] = (unsigned short)a;
+                    if (ok) {
+                        const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                        region[pos] = (unsigned short)a;
+                        if (pos < PAIR_STASH) {
+                            typedef double d2v __attribute__((ext_vector_type(2)));
+                            d2v *e = reinterpret_cast<d2v *>(stash + pos);
+                            e[0] = (d2v){xd, yd};
+                            e[1] = (d2v){zd, __hiloint2double(ft[blk][q], (int)__float_as_uint(fr[blk][q]))};
+                        }
+                    }
                     cnt += __popcll(mk);
                 }
             }
         }
+        MVX_STAMP_MAX(11);
         return cnt;
     };
 
-    // ---- B. stage: this wave prepares ITS survivors [lo, hi) of segment s0, one lane each, into rows rowbase + i ------------
-    const BlockBounds Bx = block_bounds(g, x0p), By = block_bounds(g, y0); // the reference blocks this pair lies in
-    auto stage = [&](int s0, int lo, int hi, int rowbase) {
-        for (int i0 = lo; i0 < hi; i0 += 64) { // (one trip unless a wave found more than 64 candidates)
-            const int i = i0 + lane;
-            const bool valid = i < hi;
-            int idx = 0;
-            if (valid) idx = small ? 64 * wave + i : (int)region[i];
-            const unsigned arel = (unsigned)(s0 + idx); // atom index inside the molecule
-            unsigned *row = un + (size_t)(rowbase + i) * SW;
-            if (valid) {
-                const double *cp = pa.coords + 3 * a0;
-                double p[3] = {cp[3u * arel], cp[3u * arel + 1u], cp[3u * arel + 2u]};
-                int my_type = 0;
-                bool keep = true;
-                if (pa.types) {
-                    my_type = (pa.types + a0)[arel];
-                    if (my_type < 0 || my_type >= C) keep = false;
+    // this wave's survivors and where they fall in the segment's candidate order (one barrier)
+    auto prefix = [&](int cnt, int &pre_mine) __attribute__((always_inline)) -> int {
+        if (lane == 0) wcnt[wave] = cnt;
+        __syncthreads();
+        const int v = row_prefix16(lane < NWT ? wcnt[lane] : 0); // (lanes 0-15: inclusive prefix over the waves)
+        pre_mine = wave ? __builtin_amdgcn_readlane(v, wave - 1) : 0;
+        MVX_STAMP(1);
+        return __builtin_amdgcn_readlane(v, 15);
+    };
+    // ---- B1. gather: survivors [.., ..) of this wave that fall into the round that starts at candidate r0 -> the round's rows,
+    //          in candidate (= atom) order: words 0-5 position, 6 atom-wise radius, 7 type, 13 atom index (bit 31: not stashed)
+    auto gather = [&](int cnt, int pre, int r0) __attribute__((always_inline)) {
+        for (int i = lane; i < cnt; i += 64) {
+            const int rw = pre + i - r0;
+            if (rw >= 0 && rw < PAIR_ROWS) {
+                unsigned *row = un + (size_t)rw * SW;
+                if (i < PAIR_STASH) {
+                    const uint4 *e = reinterpret_cast<const uint4 *>(stash + i);
+                    reinterpret_cast<uint4 *>(row)[0] = e[0];
+                    reinterpret_cast<uint4 *>(row)[1] = e[1];
                 }
+                row[13] = (unsigned)region[i] | (i < PAIR_STASH ? 0u : 0x80000000u);
+            }
+        }
+    };
+    // ---- B2. stage: waves 0 and 1 turn the round's n rows into records + channel weights, one lane per row (all 64 lanes
+    //          busy: the exact float64 preparation is issued once or twice per workgroup, not once per scanning wave)
+    auto stage = [&](int s0, int n) __attribute__((always_inline)) {
+        const int rw = 64 * wave + lane;
+        if (64 * wave < n) {
+            const bool valid = rw < n;
+            unsigned *row = un + (size_t)rw * SW;
+            unsigned arel = 0; // atom index inside the molecule
+            if (valid) {
+                double p[3];
+                int my_type = 0;
+                float r_atom = 0.0f;
+                bool stashed = false;
+                if (small) arel = (unsigned)rw;
+                else {
+                    const unsigned tag = row[13];
+                    arel = (unsigned)s0 + (tag & 0xffffu);
+                    stashed = (tag >> 31) == 0u;
+                }
+                if (stashed) {
+                    p[0] = *reinterpret_cast<const double *>(row);
+                    p[1] = *reinterpret_cast<const double *>(row + 2);
+                    p[2] = *reinterpret_cast<const double *>(row + 4);
+                    r_atom = __uint_as_float(row[6]);
+                    my_type = (int)row[7];
+                } else { // molecules that skip the scan, survivors beyond the stash: a trip to memory
+                    const double *cp = pa.coords + 3 * a0;
+                    p[0] = cp[3u * arel];
+                    p[1] = cp[3u * arel + 1u];
+                    p[2] = cp[3u * arel + 2u];
+                    if (pa.types) my_type = (pa.types + a0)[arel];
+                    if (pa.radii_src == RAD_ATOM) r_atom = (static_cast<const float *>(pa.radii) + a0)[arel];
+                }
+                bool keep = true;
+                if (pa.types && (my_type < 0 || my_type >= C)) keep = false;
                 float r32;
                 double rc;
                 if (pa.radii_src == RAD_SCALAR) {
                     rc = pa.radius_scalar;
                     r32 = (float)pa.radius_scalar;
                 } else {
-                    const int64_t ri = (pa.radii_src == RAD_ATOM) ? a0 + (int64_t)arel : (keep ? (int64_t)my_type : -1); // numpy/voxelizer.py:284-285
-                    r32 = ri >= 0 ? static_cast<const float *>(pa.radii)[ri] : 0.0f;
+                    if (pa.radii_src == RAD_ATOM) r32 = r_atom;
+                    else r32 = keep ? ((!small && my_type < PAIR_RTAB) ? rtab[my_type] : static_cast<const float *>(pa.radii)[my_type]) : 0.0f; // numpy/voxelizer.py:284-285
                     rc = (double)r32;
                 }
                 // features whose rows are whole 16-byte quads: this lane fetches its own row (CT / 4 loads in flight)
@@ -285,8 +369,14 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
                 keep = keep && (T >= 0.0);
                 // sub-tiles lie inside one reference block: the x / y block culls are uniform over the pair (its 4 x 4 voxels
                 // share a block: blockdim is a multiple of 8 here), the z cull over each wave's sub-tile (walk)
+                const BlockBounds Bx = block_bounds_lane(g, x0p), By = block_bounds_lane(g, y0);
                 keep = keep && block_admits(Bx, p[0], rc) && block_admits(By, p[1], rc);
-                const double rrd = (double)r32 * 1.000001 + 1e-9; // conservative window, as prep_atom's
+                // the pair's box (voxel centres), widened by the atom's radius window (conservative, as prep_atom's)
+                const double slack = 1e-6 * P.res;
+                const double bx0 = (double)x0p * P.res - P.half - slack, bx1 = (double)(x0p + 2 * SUBX - 1) * P.res - P.half + slack;
+                const double by0 = (double)y0 * P.res - P.half - slack, by1 = (double)(y0 + SUBY - 1) * P.res - P.half + slack;
+                const double bz0 = -P.half - slack, bz1 = (double)(D - 1) * P.res - P.half + slack;
+                const double rrd = (double)r32 * 1.000001 + 1e-9;
                 keep = keep && (p[0] + rrd >= bx0) && (p[0] - rrd <= bx1) && (p[1] + rrd >= by0) && (p[1] - rrd <= by1) &&
                        (p[2] + rrd >= bz0) && (p[2] - rrd <= bz1);
                 typedef double d2v __attribute__((ext_vector_type(2)));
@@ -313,68 +403,49 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
                 const bool own_row = CT >= 4 && (C & 3) == 0 && cbase + CT <= C && (reinterpret_cast<uintptr_t>(pa.features) & 15u) == 0;
                 if (!own_row) {
                     constexpr int RPI = 64 / WW;
-                    const int n = (hi - i0) < 64 ? (hi - i0) : 64;
+                    const int nw = (n - 64 * wave) < 64 ? (n - 64 * wave) : 64; // rows of this wave
                     const float *feat = static_cast<const float *>(pa.features) + a0 * C;
-                    for (int r0 = 0; r0 < n; r0 += RPI) {
-                        const int rr_ = r0 + lane / WW, j = lane % WW;
-                        if (rr_ < n) {
-                            const unsigned ar = (unsigned)(s0 + (small ? 64 * wave + i0 + rr_ : (int)region[i0 + rr_]));
+                    for (int q0 = 0; q0 < nw; q0 += RPI) {
+                        const int rr_ = q0 + lane / WW, j = lane % WW;
+                        const unsigned ar = (unsigned)__shfl((int)arel, rr_ < 64 ? rr_ : 63); // the atom of row 64 wave + rr_
+                        if (rr_ < nw) {
                             float v = 0.0f;
                             if (cbase + j < C) v = feat[(size_t)ar * C + cbase + j];
-                            un[(size_t)(rowbase + i0 + rr_) * SW + 16 + j] = __float_as_uint(v);
+                            un[(size_t)(64 * wave + rr_) * SW + 16 + j] = __float_as_uint(v);
                         }
                     }
                 }
             }
         }
         MVX_STAMP(2);
+        MVX_STAMP_MAX(12);
     };
 
-    // this wave's survivors and where they fall in the segment's candidate order
-    auto prefix = [&](int cnt, int &pre_mine) -> int {
-        if (lane == 0) wcnt[wave] = cnt;
-        __syncthreads();
-        const int c = lane < NWT ? wcnt[lane] : 0;
-        int total = 0;
-        pre_mine = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int cw = __builtin_amdgcn_readlane(c, w);
-            pre_mine += w < wave ? cw : 0;
-            total += cw;
-        }
-        MVX_STAMP(1);
-        return total;
-    };
-    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-
-    // The first round of the first segment is staged BEFORE the accumulators exist: scan and stage have the whole register
-    // file, and per-molecule calls rarely need more than this one round per pair.
-    int cnt0 = 0, pre0 = 0, total0 = 0;
-    if (N > 0) {
-        cnt0 = scan(0);
-        total0 = prefix(cnt0, pre0);
-        if (total0 > 0) {
-            stage(0, clampi(0 - pre0, 0, cnt0), clampi(PAIR_ROWS - pre0, 0, cnt0), pre0);
-            __syncthreads();
-            MVX_STAMP(3);
-        }
-    }
-
-    // (voxel centres and accumulators only from here on)
-    LaneCtx L = Ops::ctx(lane, ws, x0, y0, z0, 0, cbase, P);
+    // (voxel centres, accumulators and the row filter's per-wave constants are set up by set_walk(), which every wave calls
+    // between its share of the staging and the barrier in front of the first walk: the waves that have nothing to stage do it
+    // while waves 0 and 1 prepare the records)
+    LaneCtx L;
     typename Ops::Acc acc;
-    Ops::zero(acc);
     bool any = false;
-    // per-wave constants of the row filter: this sub-tile's z block and z window, this slab's x window
-    const int zv = z0 + SUBZ * ws;
-    const int zl = (zv + SUBZ - 1 < D - 1) ? zv + SUBZ - 1 : D - 1;
-    const int xl = (x0 + SUBX - 1 < D - 1) ? x0 + SUBX - 1 : D - 1;
-    const BlockBounds Bz = block_bounds(g, zv);
-    const double wz0 = uniform((double)zv * P.res - P.half - slack), wz1 = uniform((double)zl * P.res - P.half + slack);
-    const double wx0 = uniform((double)x0 * P.res - P.half - slack), wx1 = uniform((double)xl * P.res - P.half + slack);
+    BlockBounds Bz;
+    double wz0, wz1, wx0, wx1;
+    const int zv = z0 + SUBZ * ws; // first voxel of this wave's sub-tile
+    auto set_walk = [&]() __attribute__((always_inline)) {
+        L = Ops::ctx(lane, ws, x0, y0, z0, 0, cbase, P);
+        Ops::zero(acc);
+        const double slack = 1e-6 * P.res;
+        const int zl = (zv + SUBZ - 1 < D - 1) ? zv + SUBZ - 1 : D - 1;
+        // (wave-uniform: kept in scalar registers across the walk)
+        Bz = block_bounds_lane(g, zv);
+        Bz.lo = uniform(Bz.lo);
+        Bz.hi = uniform(Bz.hi);
+        wz0 = uniform((double)zv * P.res - P.half - slack);
+        wz1 = uniform((double)zl * P.res - P.half + slack);
+        wx0 = uniform((double)x0 * P.res - P.half - slack);
+        wx1 = uniform((double)(x0 + SUBX - 1) * P.res - P.half + slack);
+    };
     // ---- C. the rows this wave's sub-tile takes (one lane per row), then the walk ----------------------------------------
-    auto walk = [&](int n) {
+    auto walk = [&](int n) __attribute__((always_inline)) {
 #pragma unroll
         for (int half = 0; half < PAIR_ROWS / 64; ++half) {
             if (64 * half < n) {
@@ -396,28 +467,55 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
         }
         MVX_STAMP(4);
     };
-    if (total0 > 0) {
-        walk(total0 < PAIR_ROWS ? total0 : PAIR_ROWS);
-#pragma nounroll
-        for (int r0 = PAIR_ROWS; r0 < total0; r0 += PAIR_ROWS) {
-            __syncthreads(); // every wave is done with the previous round's rows
-            stage(0, clampi(r0 - pre0, 0, cnt0), clampi(r0 + PAIR_ROWS - pre0, 0, cnt0), pre0 - r0);
+
+    // The first round is staged BEFORE the accumulators exist: scan and stage have the whole register file, and
+    // per-molecule calls rarely need more than this one round per pair.
+    auto round = [&](int s0, int cnt, int pre, int total, int r0) __attribute__((always_inline)) { // (the rounds after a segment's first: cold)
+        const int n = (total - r0) < PAIR_ROWS ? (total - r0) : PAIR_ROWS;
+        __syncthreads(); // every wave is done with the previous round's rows / the segment's strips
+        gather(cnt, pre, r0);
+        __syncthreads();
+        stage(s0, n);
+        __syncthreads();
+        walk(n);
+    };
+    if (small) { // every atom is a candidate: no scan, no list - one barrier in the whole front
+        if (N > 0) stage(0, N);
+        set_walk();
+        if (N > 0) {
             __syncthreads();
-            walk((total0 - r0) < PAIR_ROWS ? (total0 - r0) : PAIR_ROWS);
+            MVX_STAMP(3);
+            walk(N);
         }
-    }
-#pragma nounroll
-    for (int s0 = SEGN; s0 < N; s0 += SEGN) { // molecules of more than 512 atoms per wave: further segments
-        __syncthreads(); // rows consumed before the scan strips overwrite them
-        const int cnt = scan(s0);
-        int pre;
-        const int total = prefix(cnt, pre);
-#pragma nounroll
-        for (int r0 = 0; r0 < total; r0 += PAIR_ROWS) {
-            __syncthreads(); // (strips / previous rows consumed)
-            stage(s0, clampi(r0 - pre, 0, cnt), clampi(r0 + PAIR_ROWS - pre, 0, cnt), pre - r0);
+    } else {
+        if (pa.radii_src == RAD_CHANNEL_BY_TYPE) // per-type radii: the table into LDS (published by the prefix barrier)
+            for (int c = tid; c < (C < PAIR_RTAB ? C : PAIR_RTAB); c += (int)blockDim.x) rtab[c] = static_cast<const float *>(pa.radii)[c];
+        // first segment, first round (the usual whole of a call): nothing of the walk is alive yet
+        const int cnt0 = scan(0);
+        int pre0;
+        const int total0 = prefix(cnt0, pre0); // (barrier: every strip has been read)
+        const int n0 = total0 < PAIR_ROWS ? total0 : PAIR_ROWS;
+        if (total0 > 0) {
+            gather(cnt0, pre0, 0);
             __syncthreads();
-            walk((total - r0) < PAIR_ROWS ? (total - r0) : PAIR_ROWS);
+            stage(0, n0);
+        }
+        set_walk();
+        if (total0 > 0) {
+            __syncthreads();
+            MVX_STAMP(3);
+            walk(n0);
+#pragma nounroll
+            for (int r0 = PAIR_ROWS; r0 < total0; r0 += PAIR_ROWS) round(0, cnt0, pre0, total0, r0);
+        }
+#pragma nounroll
+        for (int s0 = SEGN; s0 < N; s0 += SEGN) { // molecules of more than 512 atoms per wave: further segments
+            __syncthreads(); // rows consumed before the scan strips overwrite them
+            const int cnt = scan(s0);
+            int pre;
+            const int total = prefix(cnt, pre);
+#pragma nounroll
+            for (int r0 = 0; r0 < total; r0 += PAIR_ROWS) round(s0, cnt, pre, total, r0);
         }
     }
     MVX_STAMP(5);
@@ -427,6 +525,7 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
     Ops::write(acc, any ? 1 : 0, tile, tid - h * NW * 64, lane, ws, NW, b, L, x0, y0, z0, out, P);
     MVX_STAMP(6);
 #undef MVX_STAMP
+#undef MVX_STAMP_MAX
 }
 
 // ------------------------------------------------------------------------------------------------

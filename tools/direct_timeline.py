@@ -42,8 +42,8 @@ for _ in range(20):
     vox.forward(coords, cen, chan, radii, tr, rot, out_grid=grid)
 torch.cuda.synchronize()
 nwg = ((D + 3) // 4) * ((D + 3) // 4)  # voxelize_pair_kernel: one workgroup per pair of x-slabs (D % 4 == 0)
-buf = np.zeros((nwg, 8), dtype=np.uint64)
-_l.check(vox._lib.mvx_debug_read_records(vox._handle, buf.ctypes.data, nwg, 0))
+buf = np.zeros((nwg, 16), dtype=np.uint64)
+_l.check(vox._lib.mvx_debug_read_records(vox._handle, buf.ctypes.data, 2 * nwg, 0))  # (64-byte records: 16 stamps = 2)
 t = buf.astype(np.float64)
 t0 = t[:, 0].min()
 rel = (t - t0) / 1000.0  # s_memtime ticks = shader cycles; printed in kcycles (~0.45 us each at 2.2 GHz)
@@ -53,6 +53,14 @@ def stats(x):
     return f"min {x.min():6.2f}  p50 {np.median(x):6.2f}  max {x.max():6.2f}"
 print("start           ", stats(rel[:, 0]))
 print("scan (0->1)     ", stats(rel[:, 1] - rel[:, 0]))
+print("  last wave starts  ", stats(rel[:, 13] - rel[:, 0]))
+print("  prologue    0->8  ", stats(rel[:, 8] - rel[:, 0]))
+sc = t[:, 9] > 0
+if sc.any():
+    print("  loads issued 8->9 ", stats((rel[:, 9] - rel[:, 8])[sc]))
+    print("  first data  9->10 ", stats((rel[:, 10] - rel[:, 9])[sc]))
+    print("  tests (last wave) 10->11", stats((rel[:, 11] - rel[:, 10])[sc]))
+    print("  barrier+prefix 11->1    ", stats((rel[:, 1] - rel[:, 11])[sc]))
 e = ~has
 if e.any():
     print("empty: fill 5->6", stats((rel[:, 6] - rel[:, 5])[e]), " end", stats(rel[:, 6][e]))
@@ -61,6 +69,7 @@ if has.any():
     print("stage (1->2)    ", stats((rel[:, 2] - rel[:, 1])[h]))
     print("  coords in 1->7", stats((rel[:, 7] - rel[:, 1])[h]))
     print("  math+LDS  7->2", stats((rel[:, 2] - rel[:, 7])[h]))
+    print("  last wave staged 1->12", stats((rel[:, 12] - rel[:, 1])[h]))
     print("barrier (2->3)  ", stats((rel[:, 3] - rel[:, 2])[h]))
     print("walk (3->4)     ", stats((rel[:, 4] - rel[:, 3])[h]))
     print("write (5->6)    ", stats((rel[:, 6] - rel[:, 5])[h]))
