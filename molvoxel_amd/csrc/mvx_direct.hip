@@ -431,10 +431,10 @@ static hipError_t launch_direct(const DirectArgs &d, const VoxParams &p, float *
 // lane_range false - sub-tiles inside one reference block on a grid of whole 16-byte quads per row, the usual case - takes
 // voxelize_pair_kernel (mvx_pair.hip); this kernel serves the per-lane-range cases (blockdim 4, 5, 12, ...) and the grids
 // written run by run (odd dimensions, unaligned slices), for which the caller also passes lane_range = true.
-hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, bool lane_range,
-                                  hipStream_t s) {
+hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, int64_t max_atoms, float *out, int32_t ct, bool gauss,
+                                  bool lane_range, hipStream_t s) {
     if (p.NW > 8) return hipErrorInvalidConfiguration;
-    if (!lane_range) return launch_voxelize_pair(d, p, out, ct, gauss, s);
+    if (!lane_range) return launch_voxelize_pair(d, p, max_atoms, out, ct, gauss, s);
 #define MVX_CASE(CT_) \
     if (ct == CT_) return gauss ? launch_direct<CT_, true>(d, p, out, s) : launch_direct<CT_, false>(d, p, out, s);
     MVX_CASE(1)

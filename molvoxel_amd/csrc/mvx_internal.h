@@ -153,10 +153,11 @@ hipError_t launch_voxelize_grouped(const VoxArgs &a, int32_t nb, bool gauss, boo
 // float64 grids: every slab of the whole batch through the general slab loop (ct <= 16; a.p.dcap must be 64)
 hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
 // the whole call in one launch (float32 grids, NW <= 8): no workspace, no pre-pass
-hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, bool lane_range,
-                                  hipStream_t s);
+hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, int64_t max_atoms, float *out, int32_t ct, bool gauss,
+                                  bool lane_range, hipStream_t s);
 // ... the same call with two slabs per workgroup sharing one atom scan (mvx_pair.hip): aligned grids, uniform block culls
-hipError_t launch_voxelize_pair(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, hipStream_t s);
+// (max_atoms: the largest molecule of the call - sizes the per-wave candidate lists)
+hipError_t launch_voxelize_pair(const DirectArgs &d, const VoxParams &p, int64_t max_atoms, float *out, int32_t ct, bool gauss, hipStream_t s);
 void scalar_radius_constants(double radius_scalar, float sigma32, bool gauss, double *T, float *k);
 // profiled launches: the next voxelize launch on this thread carries these events on its own dispatch packet
 void set_launch_events(hipEvent_t start, hipEvent_t stop);

@@ -19,7 +19,7 @@
 // Exactness is unchanged: the float32 scan only decides which atoms are LOOKED AT (a superset, error-bounded); box cull,
 // block culls, threshold and coefficient are decided in float64 with the reference's comparisons (stage), membership per
 // voxel by d2 <= T (walk).
-// LDS map (dynamic): u16 list[2 NW][512] | PairStash stash[2 NW][48] | int wcnt[32] | float rtab[256] |
+// LDS map (dynamic): u16 list[2 NW][segw] | PairStash stash[2 NW][48] | int wcnt[32] | float rtab[256] |
 //                    union { float64 strips 2 NW x 3 KB ; rows 128 x SW words ; 2 tiles }.
 #include "mvx_device.h"
 #include "mvx_ops32.h"
@@ -29,8 +29,9 @@
 namespace mvx {
 
 constexpr int PAIR_BLOCK = 128;                           // atoms per transposition block (3 x 1 KB of coordinates)
-constexpr int PAIR_MAX_BLOCKS = 4;                        // blocks a wave scans per segment (all loads in flight: 48 registers)
-constexpr int PAIR_SEGW = PAIR_BLOCK * PAIR_MAX_BLOCKS;   // atoms per wave and segment
+constexpr int PAIR_MAX_BLOCKS = 4;                        // blocks a wave fetches at once (all loads in flight: 48 registers)
+constexpr int PAIR_SEGW_MIN = PAIR_BLOCK * PAIR_MAX_BLOCKS; // atoms per wave and segment: 512 (molecules of up to 8 192 atoms on
+constexpr int PAIR_SEGW_MAX = 2048;                         // 16 waves) ... 2 048 (32 768 atoms), chosen at launch (VoxParams::dcap)
 constexpr int PAIR_ROWS = 128;                            // candidate rows staged per round (both slabs share them)
 constexpr int PAIR_STASH = 48;                            // survivors per wave and segment whose float64 position, radius and type stay in LDS
 constexpr int PAIR_RTAB = 256;                            // per-type radii kept in LDS (forward_types with channel-wise radii)
@@ -54,12 +55,20 @@ __host__ __device__ inline int pair_tile_words(int ct, int NW) { // one slab's w
     const int cr = ct == 32 ? MX_CR : (ct < CR_F32 ? ct : CR_F32);
     return cr * RPC * row_stride_floats(NW);
 }
-static size_t pair_lds_bytes(int32_t ct, int32_t NW) {
+// atoms per wave and segment for molecules of up to max_atoms atoms: one segment whenever the list can hold it (a second
+// segment repeats scan, barriers, stage and walk with the accumulators alive: 12 000 atoms took 37.8 us in two segments of
+// 8 192 against 30.6 us binned)
+static int32_t pair_segw(int64_t max_atoms, int32_t NW) {
+    int64_t per_wave = (max_atoms + 2 * NW - 1) / (2 * NW);
+    per_wave = (per_wave + PAIR_BLOCK - 1) / PAIR_BLOCK * PAIR_BLOCK;
+    return (int32_t)std::min<int64_t>(std::max<int64_t>(per_wave, PAIR_SEGW_MIN), PAIR_SEGW_MAX);
+}
+static size_t pair_lds_bytes(int32_t ct, int32_t NW, int32_t segw) {
     const size_t strips = (size_t)2 * NW * PAIR_BLOCK * 24;
     const size_t rows = (size_t)PAIR_ROWS * cand_stride_words(ct) * 4;
     const size_t tiles = (size_t)2 * pair_tile_words(ct, NW) * 4;
     const size_t un = std::max(strips, std::max(rows, tiles));
-    return (size_t)2 * NW * (PAIR_SEGW * 2 + PAIR_STASH * sizeof(PairStash)) + 128 + PAIR_RTAB * 4 + un;
+    return (size_t)2 * NW * ((size_t)segw * 2 + PAIR_STASH * sizeof(PairStash)) + 128 + PAIR_RTAB * 4 + un;
 }
 
 typedef unsigned u4a8 __attribute__((ext_vector_type(4), aligned(8)));
@@ -87,11 +96,12 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
     const int h = wave >= NW ? 1 : 0; // which slab of the pair
     const int ws = wave - h * NW;     // this wave's sub-tile along z
     unsigned short *list = reinterpret_cast<unsigned short *>(smem);
-    PairStash *stash_all = reinterpret_cast<PairStash *>(smem + (size_t)NWT * PAIR_SEGW * 2);
+    const int SEGW = P.dcap; // atoms per wave and segment (pair_segw)
+    PairStash *stash_all = reinterpret_cast<PairStash *>(smem + (size_t)NWT * SEGW * 2);
     int *wcnt = reinterpret_cast<int *>(stash_all + (size_t)NWT * PAIR_STASH);
     float *rtab = reinterpret_cast<float *>(wcnt + 32);
     unsigned *un = reinterpret_cast<unsigned *>(rtab + PAIR_RTAB);
-    unsigned short *region = list + wave * PAIR_SEGW; // this wave's survivors, in atom order
+    unsigned short *region = list + wave * SEGW; // this wave's survivors, in atom order
     PairStash *stash = stash_all + wave * PAIR_STASH; // ... and what the scan knew about the first PAIR_STASH of them
 
     int b = (int)blockIdx.y, cc = 0;
@@ -132,14 +142,14 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
     MVX_STAMP(0);
 
     const bool small = N <= PAIR_ROWS; // ligands: no scan - every atom gets a row, the stage's own tests drop the far ones
-    const int SEGN = NWT * PAIR_SEGW;
+    const int SEGN = NWT * SEGW;
 
     // ---- A. scan of the segment that starts at atom s0 of the molecule: this wave's survivors -> region[0 .. cnt) ------------
     // (deliberately short: sixteen waves run it side by side, so every instruction here costs ~16 cycles of a call)
     auto scan = [&](int s0) __attribute__((always_inline)) -> int {
         MVX_STAMP(8);
         const int nseg = (N - s0) < SEGN ? (N - s0) : SEGN; // atoms of this segment
-        const int bpw = (nseg + PAIR_BLOCK * NWT - 1) / (PAIR_BLOCK * NWT); // blocks per wave, 1 ... PAIR_MAX_BLOCKS
+        const int bpw = (nseg + PAIR_BLOCK * NWT - 1) / (PAIR_BLOCK * NWT); // blocks per wave, 1 ... SEGW / 128
         const int wbeg = wave * bpw * PAIR_BLOCK; // first atom of this wave's share, relative to the segment
         int cnt = 0;
         if (wbeg >= nseg) return 0;
@@ -153,38 +163,41 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
         u4a8 fd[PAIR_MAX_BLOCKS][3];
         float fr[PAIR_MAX_BLOCKS][2];
         int ft[PAIR_MAX_BLOCKS][2];
+        auto issue = [&](int b0) __attribute__((always_inline)) { // the loads of blocks b0 .. b0 + 3 of this wave's share
 #pragma unroll
-        for (int blk = 0; blk < PAIR_MAX_BLOCKS; ++blk) {
+            for (int blk = 0; blk < PAIR_MAX_BLOCKS; ++blk) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                fr[blk][q] = 0.0f;
-                ft[blk][q] = 0;
-            }
-            if (blk < bpw) {
-                const unsigned ob = 24u * (unsigned)(wbeg + blk * PAIR_BLOCK) + 16u * (unsigned)lane;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const unsigned o = ob + 1024u * k;
-                    u4a8 v = *reinterpret_cast<const u4a8 *>(cb + (o < lim ? o : lim));
-                    // an odd atom count ends in the middle of a 16-byte chunk: that chunk is fetched 8 bytes early (never a
-                    // byte past the molecule), so the last coordinate arrives in the upper half
-                    if (o == lim + 8u) {
-                        v.x = v.z;
-                        v.y = v.w;
-                    }
-                    fd[blk][k] = v;
+                for (int q = 0; q < 2; ++q) {
+                    fr[blk][q] = 0.0f;
+                    ft[blk][q] = 0;
                 }
-                if (per_atom | typed) {
+                if (b0 + blk < bpw) {
+                    const unsigned ob = 24u * (unsigned)(wbeg + (b0 + blk) * PAIR_BLOCK) + 16u * (unsigned)lane;
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int a = wbeg + blk * PAIR_BLOCK + 64 * q + lane;
-                        const int64_t ag = a0 + s0 + (a < nseg ? a : nseg - 1);
-                        if (per_atom) fr[blk][q] = static_cast<const float *>(pa.radii)[ag];
-                        if (typed) ft[blk][q] = pa.types[ag];
+                    for (int k = 0; k < 3; ++k) {
+                        const unsigned o = ob + 1024u * k;
+                        u4a8 v = *reinterpret_cast<const u4a8 *>(cb + (o < lim ? o : lim));
+                        // an odd atom count ends in the middle of a 16-byte chunk: that chunk is fetched 8 bytes early (never
+                        // a byte past the molecule), so the last coordinate arrives in the upper half
+                        if (o == lim + 8u) {
+                            v.x = v.z;
+                            v.y = v.w;
+                        }
+                        fd[blk][k] = v;
+                    }
+                    if (per_atom | typed) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int a = wbeg + (b0 + blk) * PAIR_BLOCK + 64 * q + lane;
+                            const int64_t ag = a0 + s0 + (a < nseg ? a : nseg - 1);
+                            if (per_atom) fr[blk][q] = static_cast<const float *>(pa.radii)[ag];
+                            if (typed) ft[blk][q] = pa.types[ag];
+                        }
                     }
                 }
             }
-        }
+        };
+        issue(0);
         MVX_STAMP(9);
         // (under the loads) the pair's box as float32 centre and half extents: voxels x0p .. x0p + 3, y0 .. y0 + 3, whole
         // rows (the pair lies inside the grid: D % 4 == 0), minus the transform's final offset; the half extents carry the
@@ -225,51 +238,57 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
         }
         const float rbase_u = rwin_u * 1.00001f + mbase;
         double *strip = reinterpret_cast<double *>(un) + (size_t)wave * PAIR_BLOCK * 3; // this wave's transposition strip
-#pragma unroll
-        for (int blk = 0; blk < PAIR_MAX_BLOCKS; ++blk) {
-            if (blk < bpw) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    *reinterpret_cast<uint4 *>(strip + 128 * k + 2 * lane) = make_uint4(fd[blk][k].x, fd[blk][k].y, fd[blk][k].z, fd[blk][k].w);
-                if (blk == 0) MVX_STAMP(10);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int j = 64 * q + lane;
-                    const int a = wbeg + blk * PAIR_BLOCK + j;
-                    const double xd = strip[3 * j], yd = strip[3 * j + 1], zd = strip[3 * j + 2];
-                    float x = (float)xd, y = (float)yd, z = (float)zd;
-                    const float asum = fabsf(x) + fabsf(y) + fabsf(z);
-                    const float rr = mscale * asum + (per_atom ? fr[blk][q] * 1.00001f + mbase : rbase_u);
-                    if constexpr (XF) {
-                        x -= X.c0;
-                        y -= X.c1;
-                        z -= X.c2;
-                        if (X.rot) {
-                            const float u = X.m00 * x + X.m01 * y + X.m02 * z;
-                            const float v = X.m10 * x + X.m11 * y + X.m12 * z;
-                            const float w = X.m20 * x + X.m21 * y + X.m22 * z;
-                            x = u;
-                            y = v;
-                            z = w;
+#pragma nounroll
+        for (int b0 = 0;;) { // (one trip for shares of up to 512 atoms: molecules of up to 8 192 atoms on sixteen waves)
+    #pragma unroll
+            for (int blk = 0; blk < PAIR_MAX_BLOCKS; ++blk) {
+                if (b0 + blk < bpw) {
+    #pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        *reinterpret_cast<uint4 *>(strip + 128 * k + 2 * lane) = make_uint4(fd[blk][k].x, fd[blk][k].y, fd[blk][k].z, fd[blk][k].w);
+                    if (b0 + blk == 0) MVX_STAMP(10);
+    #pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int j = 64 * q + lane;
+                        const int a = wbeg + (b0 + blk) * PAIR_BLOCK + j;
+                        const double xd = strip[3 * j], yd = strip[3 * j + 1], zd = strip[3 * j + 2];
+                        float x = (float)xd, y = (float)yd, z = (float)zd;
+                        const float asum = fabsf(x) + fabsf(y) + fabsf(z);
+                        const float rr = mscale * asum + (per_atom ? fr[blk][q] * 1.00001f + mbase : rbase_u);
+                        if constexpr (XF) {
+                            x -= X.c0;
+                            y -= X.c1;
+                            z -= X.c2;
+                            if (X.rot) {
+                                const float u = X.m00 * x + X.m01 * y + X.m02 * z;
+                                const float v = X.m10 * x + X.m11 * y + X.m12 * z;
+                                const float w = X.m20 * x + X.m21 * y + X.m22 * z;
+                                x = u;
+                                y = v;
+                                z = w;
+                            }
                         }
-                    }
-                    // every test widened by the estimate's error bound; magnitudes float32 cannot hold are left to float64
-                    const bool near = (fabsf(x - ccx) <= hx + rr) & (fabsf(y - ccy) <= hy + rr) & (fabsf(z - ccz) <= hz + rr);
-                    const bool ok = (a < nseg) & (near | !(asum < 1.0e30f));
-                    const unsigned long long mk = __ballot(ok);
-                    if (ok) {
-                        const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                        region[pos] = (unsigned short)a;
-                        if (pos < PAIR_STASH) {
-                            typedef double d2v __attribute__((ext_vector_type(2)));
-                            d2v *e = reinterpret_cast<d2v *>(stash + pos);
-                            e[0] = (d2v){xd, yd};
-                            e[1] = (d2v){zd, __hiloint2double(ft[blk][q], (int)__float_as_uint(fr[blk][q]))};
+                        // every test widened by the estimate's error bound; magnitudes float32 cannot hold are left to float64
+                        const bool near = (fabsf(x - ccx) <= hx + rr) & (fabsf(y - ccy) <= hy + rr) & (fabsf(z - ccz) <= hz + rr);
+                        const bool ok = (a < nseg) & (near | !(asum < 1.0e30f));
+                        const unsigned long long mk = __ballot(ok);
+                        if (ok) {
+                            const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                            region[pos] = (unsigned short)a;
+                            if (pos < PAIR_STASH) {
+                                typedef double d2v __attribute__((ext_vector_type(2)));
+                                d2v *e = reinterpret_cast<d2v *>(stash + pos);
+                                e[0] = (d2v){xd, yd};
+                                e[1] = (d2v){zd, __hiloint2double(ft[blk][q], (int)__float_as_uint(fr[blk][q]))};
+                            }
                         }
+                        cnt += __popcll(mk);
                     }
-                    cnt += __popcll(mk);
                 }
             }
+            b0 += PAIR_MAX_BLOCKS;
+            if (b0 >= bpw) break;
+            issue(b0);
         }
         MVX_STAMP_MAX(11);
         return cnt;
@@ -532,26 +551,28 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
 // dispatch
 // ------------------------------------------------------------------------------------------------
 template <int CT, bool GAUSS, bool XF>
-static hipError_t launch_pair_t(const DirectArgs &d, const VoxParams &p, float *out, hipStream_t s) {
+static hipError_t launch_pair_t(const DirectArgs &d, const VoxParams &p, int64_t max_atoms, float *out, hipStream_t s) {
     static LdsLimit raised;
-    const size_t lds = pair_lds_bytes(CT, p.NW);
+    VoxParams q = p;
+    q.dcap = pair_segw(max_atoms, p.NW);
+    const size_t lds = pair_lds_bytes(CT, p.NW, q.dcap);
     auto kern = &voxelize_pair_kernel<CT, GAUSS, XF>;
     hipError_t e = raise_lds_limit(kern, lds, raised);
     if (e != hipSuccess) return e;
-    launch_profiled(kern, dim3((unsigned)(p.nsy * (p.nsx / 2)), (unsigned)(p.B * p.ncc)), dim3(p.NW * 128), lds, s, d, out, p);
+    launch_profiled(kern, dim3((unsigned)(p.nsy * (p.nsx / 2)), (unsigned)(p.B * p.ncc)), dim3(p.NW * 128), lds, s, d, out, q);
     return hipGetLastError();
 }
 
 // aligned float32 grids (rows of whole 16-byte quads: D % 4 == 0, so the x-slabs pair up), sub-tiles inside one reference
 // block, whole rows per slab (NW <= 8)
-hipError_t launch_voxelize_pair(const DirectArgs &d, const VoxParams &p, float *out, int32_t ct, bool gauss, hipStream_t s) {
+hipError_t launch_voxelize_pair(const DirectArgs &d, const VoxParams &p, int64_t max_atoms, float *out, int32_t ct, bool gauss, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     if (p.NW > 8 || p.nzc != 1 || !p.vec_store || (p.nsx & 1) || (long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
     const bool xf = d.pa.xforms != nullptr || d.pa.xf_one.flags != 0;
 #define MVX_CASE(CT_)                                                                                                       \
     if (ct == CT_) {                                                                                                        \
-        if (gauss) return xf ? launch_pair_t<CT_, true, true>(d, p, out, s) : launch_pair_t<CT_, true, false>(d, p, out, s);   \
-        return xf ? launch_pair_t<CT_, false, true>(d, p, out, s) : launch_pair_t<CT_, false, false>(d, p, out, s);           \
+        if (gauss) return xf ? launch_pair_t<CT_, true, true>(d, p, max_atoms, out, s) : launch_pair_t<CT_, true, false>(d, p, max_atoms, out, s);   \
+        return xf ? launch_pair_t<CT_, false, true>(d, p, max_atoms, out, s) : launch_pair_t<CT_, false, false>(d, p, max_atoms, out, s);           \
     }
     MVX_CASE(1)
     MVX_CASE(4)

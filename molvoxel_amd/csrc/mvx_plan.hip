@@ -69,8 +69,9 @@ mvx_plan plan_call(const mvx_plan_query &q, const PlanKnobs &k) {
 
     // ---- route -------------------------------------------------------------------------------------------------------
     plan_slabs(D, 8, false, k.force_nw, p);
-    // One launch for the whole call (voxelize_direct_kernel) when the per-workgroup atom scan is cheap next to the slab's
-    // stores: per-molecule forward() calls, and batches of small molecules. Bigger jobs amortise the binning pre-pass.
+    // One launch for the whole call (voxelize_pair_kernel; voxelize_direct_kernel for per-lane ranges / run-wise grids) when
+    // the per-workgroup atom scan is cheap next to the slab's stores: per-molecule forward() calls, and a few small
+    // molecules per call. Bigger jobs amortise the binning pre-pass.
     // Whole-row slabs only (D <= 64: with rows cut in two the one-launch route loses at every size measured - D = 68 / 72 /
     // 76, us per call one launch / binned: 4000-atom-density pocket 57 / 23, 65 / 24, 69 / 27; 8 atoms 24 / 18, 26 / 19,
     // 28 / 23). Channel-wise radii for features always take the grouped launch of the binned pipeline.
@@ -80,7 +81,8 @@ mvx_plan plan_call(const mvx_plan_query &q, const PlanKnobs &k) {
         else {
             const long long per_mol = (long long)p.nsx * p.nsy * p.nzc;
             const long long wgs = (long long)B * p.ncc * per_mol;
-            const long long limit = p.ncc > 1 ? DIRECT_MAX_ATOM_TESTS_CHUNKED : (wgs <= 512 ? DIRECT_MAX_ATOM_TESTS : DIRECT_MAX_ATOM_TESTS_MANY);
+            const long long limit = p.ncc > 1 ? DIRECT_MAX_ATOM_TESTS_CHUNKED
+                                              : (wgs <= 512 ? DIRECT_MAX_ATOM_TESTS : (wgs <= 1024 ? DIRECT_MAX_ATOM_TESTS_TWO : DIRECT_MAX_ATOM_TESTS_MANY));
             direct = wgs <= DIRECT_MAX_WORKGROUPS && (long long)p.ncc * per_mol * q.total_atoms <= limit;
         }
     }

@@ -42,19 +42,27 @@ constexpr int DIRECT_WAVES_PER_SIMD = 4; // voxelize_direct_kernel: 128 register
 // bytes of pre-pass data (records, keys, feature rows, slab lines: re-read ~20 times) per voxelize launch: what stays in
 // the 256 MiB Infinity Cache. One launch over 512 cfg-2 molecules (544 MB) ran at 0.654 of peak, in two chunks at 0.755.
 constexpr double MALL_BUDGET = 288.0e6;
-// One launch for the whole call (voxelize_direct_kernel) instead of prep -> xbin -> voxelize, us per call binned / direct
-// (tools/route_rule.py): 512 workgroups, 12 000 atoms 70 / 42; 1 024 workgroups 30 / 27; 2 304 (96^3) 30 / 44; 4 096 (128^3)
-// 31 / 63; 256 ligands in one call (131 072 workgroups) 640 / 2040.
-constexpr long long DIRECT_MAX_WORKGROUPS = 1536;
-// ... and at most this many atom tests (workgroups x atoms of their molecule: every workgroup scans its molecule, ~2 us per
-// million)
-constexpr long long DIRECT_MAX_ATOM_TESTS = 16ll << 20;
-// ... several channel chunks (C > 32) scan, stage and walk once per chunk: one molecule, C = 64, one launch / binned: D = 64
-// 4000 atoms 33 / 26 us, D = 48 1700 atoms 24 / 20 (0.97 M tests), D = 32 500 atoms 13 / 18 (0.13 M)
-constexpr long long DIRECT_MAX_ATOM_TESTS_CHUNKED = 400000;
-// ... launches of more than 512 workgroups (two or three molecules per call): the later molecules' scans share compute units
-// with the first's. cfg-2 density, D = 64, C = 32: two molecules 35 / 27 us, three 47 / 33; 8-atom molecules stay (18 / 20)
+// One launch for the whole call (voxelize_pair_kernel: two slabs per workgroup, one workgroup per compute unit at a time)
+// instead of prep -> xbin -> voxelize. us per call binned / one launch (tools/route_sweep.py, profiles/r04_route_sweep.txt);
+// "workgroups" below counts slabs as plan_call does (a pair kernel workgroup serves two). One molecule on a 64^3 grid, C = 32
+// (512 slabs = one round of 256 workgroups): 50 atoms 16.1 / 9.5, 4 000 19.5 / 15.0, 8 000 26.4 / 19.0, 16 000 36.5 / 28.5,
+// 24 000 48.7 / 38.2, 32 000 173 / 47.5, 48 000 (two segments) 253 / 76; C = 4: 4 000 17.8 / 10.6; 48^3: 16 000 141 / 36.6.
+// Several rounds of workgroups repeat the front (scan, stage, walk) while the binned pipeline shares its pre-pass:
+// 1 024 slabs (two pockets, or C = 64): 500 atoms each 21.0 / 20.4, 2 000 23.1 / 23.4, 4 000 25.4 / 26.7; 1 536 slabs: 27.5 / 28.8
+// ... 31.1 / 38.0; ligands (50 atoms, C = 16): 2 per call 15.7 / 10.7, 4 per call 20.3 / 17.9, 8 per call 30.7 / 31.9, 16: 51 / 83;
+// two cfg-3 molecules (576 slabs) 19.8 / 14.5, four 17.9 / 18.0.
+constexpr long long DIRECT_MAX_WORKGROUPS = 2048;
+// ... and at most this many atom tests (slabs x atoms of their molecule). One round of workgroups (up to 512 slabs): never
+// the limit in practice (131 072 atoms at 512 slabs)
+constexpr long long DIRECT_MAX_ATOM_TESTS = 64ll << 20;
+// ... two rounds (513 ... 1 024 slabs: two molecules per call)
+constexpr long long DIRECT_MAX_ATOM_TESTS_TWO = 600000;
+// ... three or four rounds (ligand-sized molecules only)
 constexpr long long DIRECT_MAX_ATOM_TESTS_MANY = 300000;
+// ... several channel chunks (C > 32) scan, stage and walk once per chunk: one molecule, C = 64, binned / one launch: D = 64
+// 500 atoms 20.6 / 20.3, 2 000 22.0 / 23.5, 4 000 24.2 / 26.6; D = 48 1 700 atoms 18.2 / 19.4 (0.98 M tests); D = 32 500 atoms
+// 14.0 / 9.3
+constexpr long long DIRECT_MAX_ATOM_TESTS_CHUNKED = 600000;
 // float64 grids of more channels than this take the matrix-core slab kernel (8 or 16 channels padded to a chunk of 32 there:
 // 1.7 / 2.9 TB/s against 2.2 / 3.2 for the general loop)
 constexpr int MX64_MIN_C = 16;

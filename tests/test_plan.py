@@ -1,6 +1,6 @@
 """The library's decision table (mvx_plan_call: route, slab plan, channel / molecule chunks, pacing, write-out path) pinned row
-by row next to the measurements that chose each row (molvoxel_amd/csrc/mvx_tuning.h, profiles/r03_odd_dimensions.txt,
-profiles/r03_round_pacing.txt). mvx_plan_call is a pure host function: no GPU is needed, nothing is launched.
+by row next to the measurements that chose each row (molvoxel_amd/csrc/mvx_tuning.h, profiles/r04_route_sweep.txt,
+profiles/r03_odd_dimensions.txt, profiles/r03_round_pacing.txt). mvx_plan_call is a pure host function: no GPU is needed, nothing is launched.
 A change of the rule must come with the measurement that justifies moving a row."""
 import pytest
 
@@ -21,7 +21,7 @@ def test_baseline_configurations():
     p = plan(64, 32, 256, 4000)
     assert (p["route"], p["nsx"], p["nsy"], p["nzc"], p["nw"], p["ct"], p["ncc"], p["nchunk"], p["pace"]) == (BINNED, 32, 16, 1, 8, 32, 1, 1, 2)
     assert p["weights_in_place"] == 1 and p["vec_store"] == 1 and p["lane_range"] == 0 and p["ct_rem"] == 0
-    # one cfg-2 pocket per forward() call: 512 workgroups, one launch (19 against 21 us binned)
+    # one cfg-2 pocket per forward() call: 512 slabs = 256 pair workgroups, one launch (15 against 19.5 us binned)
     assert plan(64, 32, 1, 4000)["route"] == DIRECT
     # cfg-1 ligand and cfg-3 (binary types, 48^3, N = 1000) as single calls: one launch
     assert plan(64, 5, 1, 33)["route"] == DIRECT
@@ -35,24 +35,39 @@ def test_baseline_configurations():
 
 
 def test_route_rule_rows():
-    """profiles/r03_odd_dimensions.txt, ROUTE_SWEEP / SMALL_BATCH_SWEEP / ONE_SWEEP tables (us per call one launch / binned)."""
+    """profiles/r04_route_sweep.txt (tools/route_sweep.py, voxelize_pair_kernel; us per call binned / one launch) and, for rows cut
+    in two, profiles/r03_odd_dimensions.txt."""
     # rows cut in two (D = 65 ... 76) never take the one-launch route: 57 / 23, 65 / 24, 69 / 27 us
     for D in (68, 72, 76):
         assert plan(D, 32)["route"] == BINNED
         assert plan(D, 32, atoms=8)["route"] == BINNED
-    # several channel chunks: one launch only up to 0.4 M atom tests - C = 64 pocket at D = 64 33 / 26 us -> binned,
-    # 8 atoms 18 / 20 -> one launch, D = 24 / 32 dense 11 / 18 -> one launch
+    # one molecule on up to 512 slabs (one round of pair workgroups): one launch at every size measured - 64^3, C = 32:
+    # 8 000 atoms 26.4 / 19.0, 24 000 48.7 / 38.2, 48 000 253 / 76; 48^3, 16 000 atoms 141 / 36.6
+    for atoms in (8, 4000, 8000, 24000, 48000):
+        assert plan(64, 32, 1, atoms)["route"] == DIRECT
+    assert plan(48, 32, 1, 16000)["route"] == DIRECT
+    # several channel chunks: one launch up to 0.6 M atom tests - C = 64 at D = 64: 500 atoms 20.6 / 20.3 -> one launch, 2 000
+    # atoms 22.0 / 23.5 and the 4 000-atom pocket 24.2 / 26.6 -> binned; D = 24 / 32 dense 14.0 / 9.3 -> one launch
     assert plan(64, 64, 1, 4000)["route"] == BINNED
+    assert plan(64, 64, 1, 2000)["route"] == BINNED
+    assert plan(64, 64, 1, 500)["route"] == DIRECT
     assert plan(64, 64, 1, 8)["route"] == DIRECT
     assert plan(24, 64)["route"] == DIRECT
-    # two or three large molecules per call (more than 512 workgroups): 35 / 27 and 48 / 33 us -> binned; 8-atom molecules stay
+    # two molecules per call (two rounds of workgroups): pockets 25.4 / 26.7 and 23.1 / 23.4 -> binned, 500-atom molecules
+    # 21.0 / 20.4 and two cfg-3 molecules (576 slabs) 19.8 / 14.5 -> one launch
     assert plan(64, 32, 2, 4000)["route"] == BINNED
+    assert plan(64, 32, 2, 2000)["route"] == BINNED
+    assert plan(64, 32, 2, 500)["route"] == DIRECT
+    assert plan(48, 4, 2, 1000, mode="types")["route"] == DIRECT
     assert plan(64, 32, 3, 4000)["route"] == BINNED
-    assert plan(64, 32, 2, 8)["route"] == DIRECT
+    # ligands: 2 per call 15.7 / 10.7, 4 per call (2 048 slabs) 20.3 / 17.9 -> one launch; 8 per call 30.7 / 31.9, 16: 51 / 83,
+    # 256 in one call 0.64 / 2.04 ms -> binned; four cfg-3 molecules 17.9 / 18.0 -> binned
+    assert plan(64, 16, 2, 50)["route"] == DIRECT
+    assert plan(64, 16, 4, 50)["route"] == DIRECT
     assert plan(64, 32, 3, 8)["route"] == DIRECT
-    # beyond 1 536 workgroups always binned (4 molecules: 61 / 39 us; 256 ligands in one call 2.04 / 0.64 ms)
-    assert plan(64, 32, 4, 8)["route"] == BINNED
+    assert plan(64, 16, 8, 50)["route"] == BINNED
     assert plan(64, 16, 256, 50)["route"] == BINNED
+    assert plan(48, 4, 4, 1000, mode="types")["route"] == BINNED
     # 96^3 and 128^3 single calls: 2 304 / 4 096 workgroups, 44 / 30 and 63 / 31 us
     assert plan(96, 32)["route"] == BINNED
     # channel-wise radii for features: always the grouped launch of the binned pipeline, chunks of 32 channels
