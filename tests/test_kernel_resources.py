@@ -82,7 +82,22 @@ def test_no_per_channel_float32_kernels_are_left(res):
     per chunk): the per-channel kernels of rounds 1-3 (200 spilled registers at 32 channels) are gone, and with them every
     float32 instantiation that carried a `chanwise` parameter."""
     assert sum(k.startswith("voxelize_kernel<") for k in res) == 48  # 5 widths x {gaussian, binary} x {plain, lane ranges} x 2 sizes + 8 grouped
-    assert sum(k.startswith("voxelize_direct_kernel<") for k in res) == 20
+    # per-molecule launches: voxelize_pair_kernel (5 widths x {gaussian, binary} x {no transform, transform}) and, for
+    # per-lane ranges / run-wise grids only, voxelize_direct_kernel (5 widths x {gaussian, binary})
+    assert sum(k.startswith("voxelize_pair_kernel<") for k in res) == 20
+    assert sum(k.startswith("voxelize_direct_kernel<") for k in res) == 10
+
+
+def test_pair_kernel_fits_one_workgroup_of_sixteen_waves(res):
+    """voxelize_pair_kernel runs 1024 threads (two slabs, sixteen waves) per workgroup: 128 registers per lane at most, and
+    the hot path (scan, stage, first walk) free of scratch - what spills is the cold multi-segment / multi-round code, which
+    runs with the accumulators alive. The bound below is what the shipped build measures plus slack; the disassembly
+    (tools/disasm.sh voxelize_pair_kernelILi32ELb1ELb0E molvoxel_amd/csrc/mvx_pair.o) shows where the scratch accesses sit."""
+    ks = {k: v for k, v in res.items() if k.startswith("voxelize_pair_kernel<")}
+    for name, r in ks.items():
+        assert r["vgpr"] <= 128, (name, r)
+        no_transform = name.endswith(", false>")
+        assert r["scratch"] <= (260 if no_transform else 480), (name, r)
 
 
 def test_narrow_kernels_hold_their_accumulator_sets_in_registers(res):
