@@ -88,6 +88,10 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
     typedef typename PairOps<CT, GAUSS>::type Ops;
     constexpr int SW = Ops::SW;
     constexpr int WW = Ops::WW; // weight words per row
+    // blocks of 128 atoms a wave fetches at once: four (48 registers of coordinates in flight), two where the transform's
+    // constants share the register file (with four the scan of the transform variants kept a dozen registers in scratch:
+    // the reference's timing loop 12.4 -> 15.1 us per call)
+    constexpr int MAXB = XF ? 2 : PAIR_MAX_BLOCKS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -160,12 +164,12 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
         const unsigned lim = 24u * (unsigned)(N - s0) - 16u;
         const bool per_atom = pa.radii_src == RAD_ATOM;
         const bool typed = pa.types != nullptr;
-        u4a8 fd[PAIR_MAX_BLOCKS][3];
-        float fr[PAIR_MAX_BLOCKS][2];
-        int ft[PAIR_MAX_BLOCKS][2];
+        u4a8 fd[MAXB][3];
+        float fr[MAXB][2];
+        int ft[MAXB][2];
         auto issue = [&](int b0) __attribute__((always_inline)) { // the loads of blocks b0 .. b0 + 3 of this wave's share
 #pragma unroll
-            for (int blk = 0; blk < PAIR_MAX_BLOCKS; ++blk) {
+            for (int blk = 0; blk < MAXB; ++blk) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     fr[blk][q] = 0.0f;
@@ -241,7 +245,7 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
 #pragma nounroll
         for (int b0 = 0;;) { // (one trip for shares of up to 512 atoms: molecules of up to 8 192 atoms on sixteen waves)
     #pragma unroll
-            for (int blk = 0; blk < PAIR_MAX_BLOCKS; ++blk) {
+            for (int blk = 0; blk < MAXB; ++blk) {
                 if (b0 + blk < bpw) {
     #pragma unroll
                     for (int k = 0; k < 3; ++k)
@@ -286,7 +290,7 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
                     }
                 }
             }
-            b0 += PAIR_MAX_BLOCKS;
+            b0 += MAXB;
             if (b0 >= bpw) break;
             issue(b0);
         }
