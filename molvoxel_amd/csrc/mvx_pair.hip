@@ -20,7 +20,7 @@
 // block culls, threshold and coefficient are decided in float64 with the reference's comparisons (stage), membership per
 // voxel by d2 <= T (walk).
 // LDS map (dynamic): u16 list[2 NW][segw] | PairStash stash[2 NW][48] | int wcnt[32] | float rtab[256] |
-//                    union { float64 strips 2 NW x 3 KB ; rows 128 x SW words ; 2 tiles }.
+//                    union { float64 strips 2 NW x 3 KB ; rows 256 x SW words ; 2 tiles }.
 #include "mvx_device.h"
 #include "mvx_ops32.h"
 
@@ -32,7 +32,9 @@ constexpr int PAIR_BLOCK = 128;                           // atoms per transposi
 constexpr int PAIR_MAX_BLOCKS = 4;                        // blocks a wave fetches at once (all loads in flight: 48 registers)
 constexpr int PAIR_SEGW_MIN = PAIR_BLOCK * PAIR_MAX_BLOCKS; // atoms per wave and segment: 512 (molecules of up to 8 192 atoms on
 constexpr int PAIR_SEGW_MAX = 2048;                         // 16 waves) ... 2 048 (32 768 atoms), chosen at launch (VoxParams::dcap)
-constexpr int PAIR_ROWS = 128;                            // candidate rows staged per round (both slabs share them)
+constexpr int PAIR_ROWS = 256;                            // candidate rows staged per round (both slabs share them), 64 per staging wave:
+                                                          // a pair of slabs at cfg-2's density holds ~62 candidates at radius 1 A, ~140 at 2 A;
+                                                          // more than a round's rows means further, cold rounds (12 000 atoms at 64^3: 25 -> 28 us)
 constexpr int PAIR_STASH = 48;                            // survivors per wave and segment whose float64 position, radius and type stay in LDS
 constexpr int PAIR_RTAB = 256;                            // per-type radii kept in LDS (forward_types with channel-wise radii)
 struct __attribute__((aligned(16))) PairStash {           // what the scan already held about a survivor: no second trip to memory
@@ -63,9 +65,10 @@ static int32_t pair_segw(int64_t max_atoms, int32_t NW) {
     per_wave = (per_wave + PAIR_BLOCK - 1) / PAIR_BLOCK * PAIR_BLOCK;
     return (int32_t)std::min<int64_t>(std::max<int64_t>(per_wave, PAIR_SEGW_MIN), PAIR_SEGW_MAX);
 }
+__host__ __device__ inline int pair_rows(int NW) { return PAIR_ROWS < 128 * NW ? PAIR_ROWS : 128 * NW; } // (64 per wave of the workgroup at most)
 static size_t pair_lds_bytes(int32_t ct, int32_t NW, int32_t segw) {
     const size_t strips = (size_t)2 * NW * PAIR_BLOCK * 24;
-    const size_t rows = (size_t)PAIR_ROWS * cand_stride_words(ct) * 4;
+    const size_t rows = (size_t)pair_rows(NW) * cand_stride_words(ct) * 4;
     const size_t tiles = (size_t)2 * pair_tile_words(ct, NW) * 4;
     const size_t un = std::max(strips, std::max(rows, tiles));
     return (size_t)2 * NW * ((size_t)segw * 2 + PAIR_STASH * sizeof(PairStash)) + 128 + PAIR_RTAB * 4 + un;
@@ -91,7 +94,7 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
     // blocks of 128 atoms a wave fetches at once: four (48 registers of coordinates in flight), two where the transform's
     // constants share the register file (with four the scan of the transform variants kept a dozen registers in scratch:
     // the reference's timing loop 12.4 -> 15.1 us per call)
-    constexpr int MAXB = XF ? 2 : PAIR_MAX_BLOCKS;
+    constexpr int HOTB = XF ? 2 : PAIR_MAX_BLOCKS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -145,12 +148,14 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
 #endif
     MVX_STAMP(0);
 
-    const bool small = N <= PAIR_ROWS; // ligands: no scan - every atom gets a row, the stage's own tests drop the far ones
+    const int ROWS = pair_rows(NW); // candidate rows per round
+    const bool small = N <= ROWS; // ligands: no scan - every atom gets a row, the stage's own tests drop the far ones
     const int SEGN = NWT * SEGW;
 
     // ---- A. scan of the segment that starts at atom s0 of the molecule: this wave's survivors -> region[0 .. cnt) ------------
     // (deliberately short: sixteen waves run it side by side, so every instruction here costs ~16 cycles of a call)
-    auto scan = [&](int s0) __attribute__((always_inline)) -> int {
+    auto scan = [&](int s0, auto blocks_tag) __attribute__((always_inline)) -> int {
+        constexpr int MAXB = decltype(blocks_tag)::value; // blocks fetched at once (fewer where the accumulators are alive)
         MVX_STAMP(8);
         const int nseg = (N - s0) < SEGN ? (N - s0) : SEGN; // atoms of this segment
         const int bpw = (nseg + PAIR_BLOCK * NWT - 1) / (PAIR_BLOCK * NWT); // blocks per wave, 1 ... SEGW / 128
@@ -312,7 +317,7 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
     auto gather = [&](int cnt, int pre, int r0) __attribute__((always_inline)) {
         for (int i = lane; i < cnt; i += 64) {
             const int rw = pre + i - r0;
-            if (rw >= 0 && rw < PAIR_ROWS) {
+            if (rw >= 0 && rw < ROWS) {
                 unsigned *row = un + (size_t)rw * SW;
                 if (i < PAIR_STASH) {
                     const uint4 *e = reinterpret_cast<const uint4 *>(stash + i);
@@ -323,9 +328,10 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
             }
         }
     };
-    // ---- B2. stage: waves 0 and 1 turn the round's n rows into records + channel weights, one lane per row (all 64 lanes
+    // ---- B2. stage: the first n / 64 waves turn the round's n rows into records + channel weights, one lane per row (all 64 lanes
     //          busy: the exact float64 preparation is issued once or twice per workgroup, not once per scanning wave)
-    auto stage = [&](int s0, int n) __attribute__((always_inline)) {
+    auto stage = [&](int s0, int n, auto own_tag) __attribute__((always_inline)) {
+        constexpr bool OWN = decltype(own_tag)::value; // feature rows fetched by the row's own lane (CT / 4 x 4 registers in flight)
         const int rw = 64 * wave + lane;
         if (64 * wave < n) {
             const bool valid = rw < n;
@@ -370,7 +376,7 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
                 }
                 // features whose rows are whole 16-byte quads: this lane fetches its own row (CT / 4 loads in flight)
                 f4a16 wq[CT >= 4 ? CT / 4 : 1];
-                const bool own_row = pa.mode == MODE_FEATURES && CT >= 4 && (C & 3) == 0 && cbase + CT <= C &&
+                const bool own_row = OWN && pa.mode == MODE_FEATURES && CT >= 4 && (C & 3) == 0 && cbase + CT <= C &&
                                      (reinterpret_cast<uintptr_t>(pa.features) & 15u) == 0;
                 if (own_row) {
                     const f4a16 *fp = reinterpret_cast<const f4a16 *>(static_cast<const float *>(pa.features) + (a0 + arel) * C + cbase);
@@ -423,7 +429,7 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
                 }
             }
             if (pa.mode == MODE_FEATURES) { // (uniform) any other feature layout: 64 / WW rows per load, one word per lane
-                const bool own_row = CT >= 4 && (C & 3) == 0 && cbase + CT <= C && (reinterpret_cast<uintptr_t>(pa.features) & 15u) == 0;
+                const bool own_row = OWN && CT >= 4 && (C & 3) == 0 && cbase + CT <= C && (reinterpret_cast<uintptr_t>(pa.features) & 15u) == 0;
                 if (!own_row) {
                     constexpr int RPI = 64 / WW;
                     const int nw = (n - 64 * wave) < 64 ? (n - 64 * wave) : 64; // rows of this wave
@@ -446,7 +452,7 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
 
     // (voxel centres, accumulators and the row filter's per-wave constants are set up by set_walk(), which every wave calls
     // between its share of the staging and the barrier in front of the first walk: the waves that have nothing to stage do it
-    // while waves 0 and 1 prepare the records)
+    // while the first one to four waves prepare the records)
     LaneCtx L;
     typename Ops::Acc acc;
     bool any = false;
@@ -494,16 +500,16 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
     // The first round is staged BEFORE the accumulators exist: scan and stage have the whole register file, and
     // per-molecule calls rarely need more than this one round per pair.
     auto round = [&](int s0, int cnt, int pre, int total, int r0) __attribute__((always_inline)) { // (the rounds after a segment's first: cold)
-        const int n = (total - r0) < PAIR_ROWS ? (total - r0) : PAIR_ROWS;
+        const int n = (total - r0) < ROWS ? (total - r0) : ROWS;
         __syncthreads(); // every wave is done with the previous round's rows / the segment's strips
         gather(cnt, pre, r0);
         __syncthreads();
-        stage(s0, n);
+        stage(s0, n, std::false_type{}); // (cold: no row prefetch beside the live accumulators)
         __syncthreads();
         walk(n);
     };
     if (small) { // every atom is a candidate: no scan, no list - one barrier in the whole front
-        if (N > 0) stage(0, N);
+        if (N > 0) stage(0, N, std::true_type{});
         set_walk();
         if (N > 0) {
             __syncthreads();
@@ -514,14 +520,14 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
         if (pa.radii_src == RAD_CHANNEL_BY_TYPE) // per-type radii: the table into LDS (published by the prefix barrier)
             for (int c = tid; c < (C < PAIR_RTAB ? C : PAIR_RTAB); c += (int)blockDim.x) rtab[c] = static_cast<const float *>(pa.radii)[c];
         // first segment, first round (the usual whole of a call): nothing of the walk is alive yet
-        const int cnt0 = scan(0);
+        const int cnt0 = scan(0, std::integral_constant<int, HOTB>{});
         int pre0;
         const int total0 = prefix(cnt0, pre0); // (barrier: every strip has been read)
-        const int n0 = total0 < PAIR_ROWS ? total0 : PAIR_ROWS;
+        const int n0 = total0 < ROWS ? total0 : ROWS;
         if (total0 > 0) {
             gather(cnt0, pre0, 0);
             __syncthreads();
-            stage(0, n0);
+            stage(0, n0, std::true_type{});
         }
         set_walk();
         if (total0 > 0) {
@@ -529,16 +535,16 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
             MVX_STAMP(3);
             walk(n0);
 #pragma nounroll
-            for (int r0 = PAIR_ROWS; r0 < total0; r0 += PAIR_ROWS) round(0, cnt0, pre0, total0, r0);
+            for (int r0 = ROWS; r0 < total0; r0 += ROWS) round(0, cnt0, pre0, total0, r0);
         }
 #pragma nounroll
         for (int s0 = SEGN; s0 < N; s0 += SEGN) { // molecules of more than 512 atoms per wave: further segments
             __syncthreads(); // rows consumed before the scan strips overwrite them
-            const int cnt = scan(s0);
+            const int cnt = scan(s0, std::integral_constant<int, 1>{}); // (cold: the accumulators are alive)
             int pre;
             const int total = prefix(cnt, pre);
 #pragma nounroll
-            for (int r0 = 0; r0 < total; r0 += PAIR_ROWS) round(s0, cnt, pre, total, r0);
+            for (int r0 = 0; r0 < total; r0 += ROWS) round(s0, cnt, pre, total, r0);
         }
     }
     MVX_STAMP(5);

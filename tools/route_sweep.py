@@ -49,11 +49,18 @@ if what in ("single", "all"):
     for D in (32, 48, 56):
         for N in (500, 4000, 16000):
             one(D, N, 32)
-    for C in (4, 16, 64, 96):
+    for C in (4, 16):
         for N in (500, 2000, 4000, 8000):
+            one(64, N, C)
+if what in ("chunks", "all"):  # channel chunks (C > 32): a loop inside the pair kernel's workgroups
+    for C in (33, 40, 64, 96, 128):
+        for N in (50, 500, 2000, 4000, 8000):
             one(64, N, C)
     one(48, 1700, 64)
     one(32, 500, 64)
+    for B in (2, 3):
+        for N in (50, 500, 4000):
+            one(64, N, 64, B)
 if what in ("multi", "all"):
     for B in (2, 3, 4, 6, 8):
         for N in (500, 2000, 4000):
