@@ -1,4 +1,7 @@
-// mvx_direct.hip - voxelize_direct_kernel: a whole per-molecule forward() call in ONE launch (gfx950).
+// mvx_direct.hip - voxelize_direct_kernel: a whole per-molecule forward() call in ONE launch, one slab per workgroup (gfx950).
+// Since round 4 only the per-lane-range instantiations are built: blockdims whose reference blocks cut through sub-tiles (4, 5,
+// 12, ...) and grids written run by run (rows that are not whole 16-byte quads). Every other per-molecule call takes
+// voxelize_pair_kernel (mvx_pair.hip), which shares one leaner scan between two slabs.
 #include "mvx_device.h"
 
 namespace mvx {

@@ -2,20 +2,28 @@
 //
 // The reference's unit of work is one molecule per forward() call (test/test_time_numpy.py:11-15; Voxelizer.forward_features /
 // forward_types / forward_single, numpy/voxelizer.py:97-169, 240-315, 370-436). Such a call is a chain of latencies, not
-// work: launch -> coordinates -> which atoms reach this slab -> their records and weights -> walk -> stores. This kernel
-// replaces voxelize_direct_kernel (mvx_direct.hip, kept for the per-lane-range / run-wise variants) on that path. What
-// its phase timeline showed (tools/direct_timeline.py, cfg-2: scan 12.0 of a workgroup's 25.6 kcycles, 21 of 27 on the
-// reference's own timing loop) and what is different here:
-//   * the scan was vector-ALU work, ~90 instructions per 64 atoms (64-bit address clamps per load, spilled scalars read back
-//     lane by lane, scratch traffic inside the loop). Here: every load of a wave's share is issued up front as 16-byte
-//     loads with 32-bit offsets from one scalar base (3 per 128 atoms), and the test is ~30 instructions per 64 atoms;
-//   * every workgroup tested every atom. Here a workgroup owns TWO slabs side by side along x (4 x 4 x 8 NW voxels, 2 NW
-//     waves = up to 1024 threads, one workgroup per compute unit): one scan, one staged set of rows for both;
-//   * records were prepared by 8 lanes per wave from a merged list that every lane searched. Here the wave that found a
-//     candidate prepares it, one lane per candidate (its region of the list, its prefix): rows land in atom order without a
-//     lookup, and the exact float64 preparation runs once per wave instead of once per slot group;
-//   * the walk is the batched kernels' (OpsMx32 on the matrix cores for 32-channel chunks, OpsPair below that), so the
-//     sums are the same float32 chains in atom order: bit-identical to every other route.
+// work: launch -> coordinates -> which atoms reach this slab -> their records and weights -> walk -> stores, in front of
+// ~5.5 us of HBM drain for a cfg-2 grid. This kernel replaces voxelize_direct_kernel (mvx_direct.hip, kept for the
+// per-lane-range / run-wise variants) on that path: cfg-2 call 20.5 -> 14.9 us, the reference's timing loop 17.9 -> 12.9
+// (profiles/r04_single_calls.txt). What the old kernel's phase timeline showed (tools/direct_timeline.py, cfg-2: scan 12.0 of
+// a workgroup's 25.6 kcycles, 21 of 27 on the reference's own timing loop) and the rules this one is built on:
+//   * Sixteen waves run the front side by side on one compute unit, so every instruction of it costs ~16 cycles of the call:
+//     the front is bound by its INSTRUCTION COUNT per compute unit, not by memory latency (stashing data to save a second
+//     trip to memory, prefetching rows during the scan: both measured slower until the instruction count came down).
+//   * A workgroup owns TWO slabs side by side along x (4 x 4 x 8 NW voxels, 2 NW waves = up to 1024 threads, one workgroup
+//     per compute unit): one scan, one staged set of rows for both - half the scan work of a workgroup per slab.
+//   * Scan: every load of a wave's share is issued before anything else (16-byte loads, 32-bit offsets from one scalar
+//     base, 3 per 128 atoms), the box constants are computed under them, the test is ~30 instructions per 64 atoms. What
+//     the scan held about a survivor (float64 position, atom-wise radius, type) stays in LDS: no second trip to memory.
+//   * Stage: the survivors of all waves are gathered into rows in candidate (= atom) order - prefix over the waves by DPP -
+//     and the FIRST one to four waves prepare them, one lane per row, all 64 lanes busy: the exact float64 preparation is
+//     issued once or twice per workgroup instead of sixteen times with ~4 active lanes. The other waves set up their walk
+//     (voxel centres, accumulators, filter constants) meanwhile.
+//   * Walk and write-out are the batched kernels' (OpsMx32 on the matrix cores for 32-channel chunks, OpsPair below that),
+//     so the sums are the same float32 chains in atom order: bit-identical to every other route.
+//   * No scratch: the rare rounds / segments that run with the accumulators alive use lighter variants of scan and stage
+//     (one block in flight, no per-lane row prefetch). A per-wave private segment of a few hundred bytes throttles the waves
+//     a launch may have in flight (an in-kernel loop over channel chunks that needed 452 B: cfg-2 kernel 13.8 -> 18.0 us).
 // Exactness is unchanged: the float32 scan only decides which atoms are LOOKED AT (a superset, error-bounded); box cull,
 // block culls, threshold and coefficient are decided in float64 with the reference's comparisons (stage), membership per
 // voxel by d2 <= T (walk).
