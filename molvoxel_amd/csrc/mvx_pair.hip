@@ -586,6 +586,7 @@ static hipError_t launch_pair_t(const DirectArgs &d, const VoxParams &p, int64_t
 hipError_t launch_voxelize_pair(const DirectArgs &d, const VoxParams &p, int64_t max_atoms, float *out, int32_t ct, bool gauss, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     if (p.NW > 8 || p.nzc != 1 || !p.vec_store || (p.nsx & 1) || (long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
+    if (max_atoms > (int64_t)100000000) return hipErrorInvalidConfiguration; // (24-byte rows addressed with 32-bit offsets; plan_call stops at 131 072 atoms)
     const bool xf = d.pa.xforms != nullptr || d.pa.xf_one.flags != 0;
 #define MVX_CASE(CT_)                                                                                                       \
     if (ct == CT_) {                                                                                                        \
