@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
     // blocks of 128 atoms a wave fetches at once: four (48 registers of coordinates in flight), two where the transform's
     // constants share the register file (with four the scan of the transform variants kept a dozen registers in scratch:
     // the reference's timing loop 12.4 -> 15.1 us per call)
-    constexpr int HOTB = XF ? 2 : PAIR_MAX_BLOCKS;
+    constexpr int HOTB = XF ? 3 : PAIR_MAX_BLOCKS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -143,6 +143,17 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
     if constexpr (XF) {
         xf = pa.xf_one;
         if (pa.xforms) xf = pa.xforms[b];
+        // a device-resident centre (the reference's timing loop hands `center` over as a tensor): fetched ONCE, through the
+        // scalar cache, instead of by a vector load in front of the scan's constants and another in front of the stage's
+        // float64 transform (each a dependent trip to L2 on the critical path). The values were written before this launch.
+        if (xf.flags & MVX_XF_CENTER_PTR) {
+            typedef const double __attribute__((address_space(4))) *const_f64;
+            const const_f64 cp = (const_f64)(reinterpret_cast<uintptr_t>(xf.center_ptr));
+            xf.center[0] = cp[0];
+            xf.center[1] = cp[1];
+            xf.center[2] = cp[2];
+            xf.flags &= ~(uint32_t)MVX_XF_CENTER_PTR;
+        }
     }
 #ifdef MVX_DIAG // per-workgroup s_memtime stamps into the (otherwise unused) record buffer: diagnostic builds only
     // (16 slots per workgroup = the 8 per slab the host allocates, zeroed before the launch; slots 11-13 take the LATEST wave's time)

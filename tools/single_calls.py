@@ -30,6 +30,10 @@ if name == "harness":  # test/test_time_numpy.py: 10gs complex, 48^3, C = 10, ra
     vox = molvoxel_amd.create_voxelizer(0.5, 48, library="hip")
     coords, cen = vox.asarray(xyz, "coords"), vox.asarray(center, "center")
     chan, radii, C_ = vox.asarray(feats, "features"), 1.0, 10
+    if os.environ.get("MODE") == "types":  # MODE=single|types python3 tools/single_calls.py harness
+        chan = vox.asarray(types, "types")
+    elif os.environ.get("MODE") == "single":
+        chan, C_ = None, 1
     tr, rot = 0.5, True
 else:
     wl = {"cfg1": lambda: W.cfg1(pc["ligand_xyz"], pc["ligand_feat5"]), "cfg2": W.cfg2, "cfg3": W.cfg3, "cfg5": W.cfg5}[name]()
