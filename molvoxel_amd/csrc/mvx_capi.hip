@@ -567,7 +567,7 @@ int run(mvx_handle *h, const RunArgs &r) {
                 if (r.in_kind == MVX_HOST) resolve_host_centers(&da.pa.xf_one, 1);
             }
         }
-        if ((rc = timed_launch(h, s, [&] { return launch_voxelize_direct(da, va.p, max_atoms, static_cast<float *>(d_out), ct, gauss, lane_range, s); })))
+        if ((rc = timed_launch(h, s, [&] { return launch_voxelize_direct(da, va.p, max_atoms, static_cast<float *>(d_out), ct, gauss, lr_blocks, s); })))
             return rc;
         if (in.slot) {
             HIP_TRY(hipEventRecord(in.slot->done, s));

@@ -1,6 +1,6 @@
 // mvx_direct.hip - voxelize_direct_kernel: a whole per-molecule forward() call in ONE launch, one slab per workgroup (gfx950).
 // Since round 4 only the per-lane-range instantiations are built: blockdims whose reference blocks cut through sub-tiles (4, 5,
-// 12, ...) and grids written run by run (rows that are not whole 16-byte quads). Every other per-molecule call takes
+// 12, ...). Every other per-molecule call takes
 // voxelize_pair_kernel (mvx_pair.hip), which shares one leaner scan between two slabs.
 #include "mvx_device.h"
 
@@ -431,9 +431,8 @@ static hipError_t launch_direct(const DirectArgs &d, const VoxParams &p, float *
     return hipGetLastError();
 }
 
-// lane_range false - sub-tiles inside one reference block on a grid of whole 16-byte quads per row, the usual case - takes
-// voxelize_pair_kernel (mvx_pair.hip); this kernel serves the per-lane-range cases (blockdim 4, 5, 12, ...) and the grids
-// written run by run (odd dimensions, unaligned slices), for which the caller also passes lane_range = true.
+// lane_range false - sub-tiles inside one reference block, the usual case - takes voxelize_pair_kernel (mvx_pair.hip), aligned
+// grid or not; this kernel serves the per-lane-range cases (blockdim 4, 5, 12, ...).
 hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, int64_t max_atoms, float *out, int32_t ct, bool gauss,
                                   bool lane_range, hipStream_t s) {
     if (p.NW > 8) return hipErrorInvalidConfiguration;

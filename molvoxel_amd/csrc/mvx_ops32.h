@@ -226,10 +226,10 @@ struct OpsMx32 {
 // fma(0, w, acc) = acc). Its rows (<= 32 words) are staged two per load instruction with addresses formed on the
 // vector ALU (stage_round_v): the eight scalar index loads and 64-bit scalar address computations per wave were
 // half of the scalar instructions.
-template <int CT_, bool GAUSS>
+template <int CT_, bool GAUSS, bool RUNS_ = false>
 struct OpsPair {
     static constexpr int CT = CT_;
-    static constexpr bool RUNS = false;
+    static constexpr bool RUNS = RUNS_; // carries the run-wise write-out (store_runs): the per-molecule kernel only
     static constexpr bool GROUPED = false;
     static constexpr bool VSTAGE = true;
     // no per-wave sphere / box cull of the staged rows (reaches_subtile): ~35 vector instructions per wave and round to drop
@@ -309,8 +309,8 @@ struct OpsPair {
     }
     static __device__ __forceinline__ void write(const Acc &acc, bool any, unsigned *un, int tid, int lane, int wave, int NW,
                                                  int b, const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
-        write_slab<CT, false>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
-                              static_cast<float *>(out), P);
+        write_slab<CT, RUNS>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
+                             static_cast<float *>(out), P);
     }
 };
 

@@ -52,13 +52,15 @@ struct __attribute__((aligned(16))) PairStash {           // what the scan alrea
 };
 static_assert(sizeof(PairStash) == 32, "two 16-byte LDS writes per survivor");
 
+// (the write-outs carry the run-wise path - store_runs - beside the 16-byte one: grids whose rows are not whole quads, odd
+// dimensions and unaligned slices of a batch grid, take this kernel too)
 template <int CT, bool GAUSS>
 struct PairOps {
-    typedef OpsPair<CT, GAUSS> type;
+    typedef OpsPair<CT, GAUSS, true> type;
 };
 template <bool GAUSS>
 struct PairOps<32, GAUSS> {
-    typedef OpsMx32<GAUSS, false, false, false> type;
+    typedef OpsMx32<GAUSS, false, false, true> type;
 };
 
 __host__ __device__ inline int pair_tile_words(int ct, int NW) { // one slab's write-out tile (Ops::write)
@@ -228,7 +230,8 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
         issue(0);
         MVX_STAMP(9);
         // (under the loads) the pair's box as float32 centre and half extents: voxels x0p .. x0p + 3, y0 .. y0 + 3, whole
-        // rows (the pair lies inside the grid: D % 4 == 0), minus the transform's final offset; the half extents carry the
+        // rows (a pair that sticks out of the grid - D % 4 != 0 - is tested with its full box: still a superset), minus the
+        // transform's final offset; the half extents carry the
         // rounding of this very estimate (a few 1e-7 of the magnitudes involved). The atom's side of the error bound is
         // SCAN_MARGIN times its magnitude (make_xform_f32 in mvx_device.h); membership is never decided here.
         const float resf = (float)P.res, halff = (float)P.half;
@@ -506,8 +509,10 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
                     const double rc = *reinterpret_cast<const double *>(r + 10);
                     const double rr = (double)__uint_as_float(r[12]);
                     kept = rr >= 0.0;
-                    ok = kept && (zv < D) && block_admits(Bz, pz, rc) && (pz + rr >= wz0) && (pz - rr <= wz1) && (pxr + rr >= wx0) &&
-                         (pxr - rr <= wx1);
+                    // (zv < D: sub-tiles past the end of a row; x0 < D: the second slab of the last pair when the grid has an odd
+                    // number of x-slabs - such waves walk nothing and their write-out stores nothing, but they pass every barrier)
+                    ok = kept && (zv < D) && (x0 < D) && block_admits(Bz, pz, rc) && (pz + rr >= wz0) && (pz - rr <= wz1) &&
+                         (pxr + rr >= wx0) && (pxr - rr <= wx1);
                 }
                 any = any || __ballot(kept) != 0ull; // (the same rows in every wave: workgroup-uniform)
                 Ops::walk(acc, __ballot(ok), un + (size_t)64 * half * SW, lane, L, P, nullptr, nullptr);
@@ -588,15 +593,15 @@ static hipError_t launch_pair_t(const DirectArgs &d, const VoxParams &p, int64_t
     auto kern = &voxelize_pair_kernel<CT, GAUSS, XF>;
     hipError_t e = raise_lds_limit(kern, lds, raised);
     if (e != hipSuccess) return e;
-    launch_profiled(kern, dim3((unsigned)(p.nsy * (p.nsx / 2)), (unsigned)(p.B * p.ncc)), dim3(p.NW * 128), lds, s, d, out, q);
+    launch_profiled(kern, dim3((unsigned)(p.nsy * ((p.nsx + 1) / 2)), (unsigned)(p.B * p.ncc)), dim3(p.NW * 128), lds, s, d, out, q);
     return hipGetLastError();
 }
 
-// aligned float32 grids (rows of whole 16-byte quads: D % 4 == 0, so the x-slabs pair up), sub-tiles inside one reference
-// block, whole rows per slab (NW <= 8)
+// float32 grids with whole rows per slab (NW <= 8) and sub-tiles inside one reference block; rows of whole 16-byte quads or
+// not (run-wise write-out), an even number of x-slabs or not (the last pair's second slab then lies outside the grid)
 hipError_t launch_voxelize_pair(const DirectArgs &d, const VoxParams &p, int64_t max_atoms, float *out, int32_t ct, bool gauss, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
-    if (p.NW > 8 || p.nzc != 1 || !p.vec_store || (p.nsx & 1) || (long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
+    if (p.NW > 8 || p.nzc != 1 || (long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
     if (max_atoms > (int64_t)100000000) return hipErrorInvalidConfiguration; // (24-byte rows addressed with 32-bit offsets; plan_call stops at 131 072 atoms)
     const bool xf = d.pa.xforms != nullptr || d.pa.xf_one.flags != 0;
 #define MVX_CASE(CT_)                                                                                                       \
