@@ -15,6 +15,8 @@
 #include "mvx_device.h"
 #include "mvx_ops32.h"
 
+#include <algorithm>
+
 namespace mvx {
 
 #ifdef MVX_DIAG
@@ -139,24 +141,31 @@ __global__ void __launch_bounds__(512, narrow_waves_per_simd(CT, NSUB))
         const int RW = 8 * NS < 64 ? 8 * NS : 64; // rows staged per round
         for (int e0 = 0; e0 <= n; e0 += RW) {
             if (e0 > 0) __syncthreads(); // every wave is done with the previous round's rows
-            {   // stage: the round's entries one per lane, rows two per load instruction
+            {   // stage: the round's entries one per lane, rows two per load instruction. Branch-free inside: a slot without a
+                // candidate fetches the molecule's first row instead and lands in a dump row behind the round's rows (sixteen
+                // exec-mask branches per wave before: 142 scalar instructions in this block for the D = 48 kernel)
                 const int e = e0 + lane;
                 int ai = 0;
                 if (lane < RW && e >= 1 && e <= n) ai = (int)(e < SLOTS ? line[e].x : ext[e - SLOTS].x);
-                const int lo = 1 - e0, hi = n - e0; // slot sl holds a candidate iff lo <= sl <= hi and sl < RW
-                for (int ub = 0; 2 * ub * NWV < RW; ub += 8) { // (one trip for 4 waves: 8 loads in flight)
-                    unsigned v[8];
+                const int lo = (1 - e0) > 0 ? (1 - e0) : 0, hi = (n - e0) < RW - 1 ? (n - e0) : RW - 1; // slot sl holds a candidate iff lo <= sl <= hi
+                const unsigned span = (unsigned)(hi - lo);
+                const int dsl = 2 * NWV;
+                for (int sl0 = wave + NWV * half; sl0 - NWV * half - wave < RW; sl0 += 8 * dsl) { // (one trip for 4 waves: 8 loads in flight)
+                    unsigned a[8], v[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int sl = wave + NWV * (2 * (ub + i) + half);
-                        const unsigned a = (unsigned)__builtin_amdgcn_ds_bpermute(4 * sl, ai);
-                        v[i] = 0u;
-                        if (sl >= lo && sl <= hi && sl < RW && used) v[i] = base[(size_t)(first + a) * stride];
+                    for (int i = 0; i < 8; ++i) { // (every lane takes part: ds_bpermute reads nothing from a masked-off source lane)
+                        const int sl = sl0 + dsl * i;
+                        const unsigned ar = (unsigned)__builtin_amdgcn_ds_bpermute(4 * sl, ai);
+                        a[i] = (unsigned)(sl - lo) <= span ? ar : 0u;
                     }
+                    if (used) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int sl = wave + NWV * (2 * (ub + i) + half);
-                        if (sl >= lo && sl <= hi && sl < RW && used) un[sl * SW + wd] = v[i];
+                        for (int i = 0; i < 8; ++i) v[i] = base[(size_t)(first + a[i]) * stride];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int sl = sl0 + dsl * i;
+                            un[((unsigned)(sl - lo) <= span ? sl : RW) * SW + wd] = v[i];
+                        }
                     }
                 }
             }
@@ -185,7 +194,10 @@ __global__ void __launch_bounds__(512, narrow_waves_per_simd(CT, NSUB))
     const int D = P.D, RS = row_stride_floats(NS);
     const size_t D2 = (size_t)D * D, D3 = D2 * D;
     const int F4 = (SUBZ / 4) * NS;          // float4 slots per row
-    const int q = tid % F4, rfirst = tid / F4; // this thread's slot and first row; rows advance by nthr / F4 = 32 / NSUB per pass
+    // this thread's slot and first row; rows advance by nthr / F4 = 32 / NSUB per pass. (tid / F4 without the ~40-instruction
+    // integer division: (tid + 0.5) / F4 lies at least 1 / 64 away from every integer, far beyond the float rounding)
+    const int rfirst = (int)(((float)tid + 0.5f) * __frcp_rn((float)F4));
+    const int q = tid - rfirst * F4;
     constexpr int CPP = 32 / NSUB / RPC;       // ... i.e. by CPP = 2 | 1 channels
     static_assert(NSUB == 2 || NSUB == 4, "read-back passes of whole channels");
     const int zq = z0 + 4 * q;
@@ -334,10 +346,11 @@ struct LaunchFn {
             const int nsub = a.narrow_sub > 0 ? a.narrow_sub : ((CT <= 4 && p.NW % 4 == 0) ? 4 : 2);
             if (nsub > 1 && p.NW % nsub == 0 && p.vec_store) {
                 static LdsLimit raised_n;
+                const size_t lds_n = std::max(lds, (size_t)65 * cand_stride_words(CT) * 4); // (64 rows + the staging's dump row)
                 auto launch_n = [&](auto kn) {
-                    hipError_t en = raise_lds_limit(kn, lds, raised_n);
+                    hipError_t en = raise_lds_limit(kn, lds_n, raised_n);
                     if (en != hipSuccess) return en;
-                    launch_profiled(kn, dim3(slab_grid_x(p), (unsigned)(nb * p.ncc)), dim3(p.NW / nsub * 64), lds, s, a.rec, a.w, a.slist,
+                    launch_profiled(kn, dim3(slab_grid_x(p), (unsigned)(nb * p.ncc)), dim3(p.NW / nsub * 64), lds_n, s, a.rec, a.w, a.slist,
                                     a.slist_ext, static_cast<float *>(a.out), a.p);
                     return hipGetLastError();
                 };
