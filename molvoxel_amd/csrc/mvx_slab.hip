@@ -152,20 +152,22 @@ __global__ void __launch_bounds__(512, narrow_waves_per_simd(CT, NSUB))
                 const int dsl = 2 * NWV;
                 for (int sl0 = wave + NWV * half; sl0 - NWV * half - wave < RW; sl0 += 8 * dsl) { // (one trip for 4 waves: 8 loads in flight)
                     unsigned a[8], v[8];
+                    int slot[8];
+                    int sl = sl0;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { // (every lane takes part: ds_bpermute reads nothing from a masked-off source lane)
-                        const int sl = sl0 + dsl * i;
                         const unsigned ar = (unsigned)__builtin_amdgcn_ds_bpermute(4 * sl, ai);
-                        a[i] = (unsigned)(sl - lo) <= span ? ar : 0u;
+                        const bool in = (unsigned)(sl - lo) <= span;
+                        a[i] = in ? ar : 0u;
+                        slot[i] = in ? sl : RW;
+                        sl += dsl;
+                        asm volatile("" : "+v"(sl)); // (one add per slot: left alone the compiler rebuilds wave + NWV * (half + 2 i) with a quarter-rate multiply each)
                     }
                     if (used) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) v[i] = base[(size_t)(first + a[i]) * stride];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int sl = sl0 + dsl * i;
-                            un[((unsigned)(sl - lo) <= span ? sl : RW) * SW + wd] = v[i];
-                        }
+                        for (int i = 0; i < 8; ++i) un[slot[i] * SW + wd] = v[i];
                     }
                 }
             }
