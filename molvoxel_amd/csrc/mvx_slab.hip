@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : BIG_WAVES_PER_SIMD))
 // Waves per SIMD the kernel is compiled for: its natural register need with two sub-tiles is 66 / 72 / 80 for 1 / 4 / 8
 // channels (accumulator sets, eight row loads in flight); at the 64 of voxelize_kernel it spilled 1 ... 17 registers.
 // (16 channels: 96 registers and no gain over one sub-tile per wave, 0.228 ms both - they keep voxelize_kernel.)
-constexpr int narrow_waves_per_simd(int ct, int nsub) { return ct * nsub <= 8 ? 7 : (ct * nsub <= 16 && nsub == 2 ? 6 : 5); }
+constexpr int narrow_waves_per_simd(int ct, int nsub) { return 8; }
 template <int CT, bool GAUSS, int NSUB>
 __global__ void __launch_bounds__(512, narrow_waves_per_simd(CT, NSUB))
     voxelize_narrow_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
