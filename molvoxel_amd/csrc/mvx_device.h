@@ -912,20 +912,27 @@ __device__ __forceinline__ void stage_round_v(const uint2 *__restrict__ line, co
     const unsigned *base = wd < 16 ? rec + wd : w + (L.cbase + wd - 16);
     const unsigned stride = wd < 16 ? 16u : (unsigned)P.w_stride; // (32-bit operands: one v_mad_u64_u32 per row address)
     const unsigned first = (unsigned)a0;                          // (atom indices fit 31 bits: validate())
-    const int lo = 1 - e0, hi = n_line - e0; // slot sl holds a candidate iff lo <= sl <= hi (and sl < 64)
-    unsigned v[4];
+    // slot sl holds a candidate iff lo <= sl <= hi. Branch-free: a slot without one fetches the molecule's first row and lands in
+    // a dump row behind the 64 rows of a round (the launcher allocates it) - eight exec-mask branches per wave before
+    const int lo = (1 - e0) > 0 ? (1 - e0) : 0, hi = (n_line - e0) < 63 ? (n_line - e0) : 63;
+    const unsigned span = (unsigned)(hi - lo);
+    unsigned a[4], v[4];
+    int slot[4];
+    int sl = wave + NW * half; // this lane's row slot <-> entry e0 + sl
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int sl = wave + NW * (2 * u + half); // this lane's row slot <-> entry e0 + sl
-        const unsigned a = (unsigned)__builtin_amdgcn_ds_bpermute(4 * sl, ai); // (slots beyond the round read some other lane's entry: masked)
-        const bool in = sl >= lo && sl <= hi && (!BIG || sl < 64) && used;
-        v[u] = 0u;
-        if (in) v[u] = base[(size_t)(first + a) * stride];
+        const unsigned ar = (unsigned)__builtin_amdgcn_ds_bpermute(4 * sl, ai); // (slots beyond the round read some other lane's entry: masked)
+        const bool in = (unsigned)(sl - lo) <= span;
+        a[u] = in ? ar : 0u;
+        slot[u] = in ? sl : 64;
+        sl += 2 * NW;
+        asm volatile("" : "+v"(sl)); // (one add per slot instead of a quarter-rate multiply)
     }
+    if (used) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int sl = wave + NW * (2 * u + half);
-        if (sl >= lo && sl <= hi && (!BIG || sl < 64) && used) un[sl * SW + wd] = v[u];
+        for (int u = 0; u < 4; ++u) v[u] = base[(size_t)(first + a[u]) * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) un[slot[u] * SW + wd] = v[u];
     }
 }
 

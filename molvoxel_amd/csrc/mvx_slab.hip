@@ -342,13 +342,14 @@ struct LaunchFn {
         if ((long long)nb * p.ncc > 65535) return hipErrorInvalidConfiguration;
         static LdsLimit raised;
         constexpr bool mx = mx_kernel<CT, GAUSS, LANE_RANGE>();
-        const size_t lds = mx ? voxelize_mx_lds_bytes(p.NW) : voxelize_lds_bytes(CT, p.NW, CR_F32);
+        size_t lds = mx ? voxelize_mx_lds_bytes(p.NW) : voxelize_lds_bytes(CT, p.NW, CR_F32);
+        if (CT < 32 && !LANE_RANGE) lds = std::max(lds, (size_t)65 * cand_stride_words(CT) * 4); // (the vector staging's dump row: stage_round_v)
         if constexpr (CT < 16 && !LANE_RANGE) { // narrow chunks: several sub-tiles per wave (voxelize_narrow_kernel)
             // four where the accumulator sets fit (1 or 4 channels) and the row is a multiple of four sub-tiles, else two
             const int nsub = a.narrow_sub > 0 ? a.narrow_sub : ((CT <= 4 && p.NW % 4 == 0) ? 4 : 2);
             if (nsub > 1 && p.NW % nsub == 0 && p.vec_store) {
                 static LdsLimit raised_n;
-                const size_t lds_n = std::max(lds, (size_t)65 * cand_stride_words(CT) * 4); // (64 rows + the staging's dump row)
+                const size_t lds_n = lds; // (64 rows + the staging's dump row)
                 auto launch_n = [&](auto kn) {
                     hipError_t en = raise_lds_limit(kn, lds_n, raised_n);
                     if (en != hipSuccess) return en;
