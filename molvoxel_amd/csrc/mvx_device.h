@@ -639,8 +639,11 @@ __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], b
     const int RS = row_stride_floats(NW);
     const size_t D2 = (size_t)D * D, D3 = D2 * D;
     const int F4 = (SUBZ / 4) * NW; // float4 slots per row
-    const int q = tid % F4;         // float4 slot inside a row
-    const int rfirst = tid / F4;    // row of this thread in pass 0; rows advance by 4 channels (4*RPC rows) per pass
+    // row of this thread in pass 0 (rows advance by 4 channels = 4*RPC rows per pass) and its float4 slot inside the row.
+    // (tid / F4 by a float reciprocal: (tid + 0.5) / F4 lies at least 1 / 64 away from every integer for tid < 1024, F4 <= 32 -
+    // the integer division by a run-time value is ~40 instructions per wave)
+    const int rfirst = (int)(((float)tid + 0.5f) * __frcp_rn((float)F4));
+    const int q = tid - rfirst * F4;
     const int zq = z0 + 4 * q;
     const int sxx = (rfirst >> SUBY_SH) & (SUBX - 1), syy = rfirst & (SUBY - 1), cfirst = rfirst / RPC;
     const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);

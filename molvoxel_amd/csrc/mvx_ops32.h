@@ -140,7 +140,8 @@ struct OpsMx32 {
         const size_t D2 = (size_t)D * D, D3 = D2 * D;
         // read-back exactly as write_slab: thread t takes float4 slot q of row rfirst (+ 4 channels per pass)
         const int F4 = (SUBZ / 4) * NW;
-        const int q = tid % F4, rfirst = tid / F4, zq = z0 + 4 * q;
+        const int rfirst = (int)(((float)tid + 0.5f) * __frcp_rn((float)F4)); // (= tid / F4 without the integer division: write_slab)
+        const int q = tid - rfirst * F4, zq = z0 + 4 * q;
         const int sxx = (rfirst >> SUBY_SH) & (SUBX - 1), syy = rfirst & (SUBY - 1), cfirst = rfirst / RPC;
         const bool vox_ok = (x0 + sxx < D) && (y0 + syy < D) && (zq < D);
         float *dst0 = out + ((size_t)b * P.C + L.cbase + cfirst) * D3 + (size_t)(x0 + sxx) * D2 + (size_t)(y0 + syy) * D + zq;
