@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r4soak2; mkdir -p $O
+O=gpurun_out/soak; mkdir -p $O
 timeout -k 10 280 python3 tools/soak.py 600000 6000 > $O/single.txt 2>&1; tail -2 $O/single.txt
 timeout -k 10 200 python3 tools/soak.py batches 600000 300 > $O/batches.txt 2>&1; tail -2 $O/batches.txt
 timeout -k 10 330 python3 tools/soak.py routes 600000 30000 > $O/routes.txt 2>&1; tail -2 $O/routes.txt

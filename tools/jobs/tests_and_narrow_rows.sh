@@ -1,6 +1,6 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r4u; mkdir -p $O
+O=gpurun_out/narrow; mkdir -p $O
 timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $O/tests.log 2>&1 || { tail -60 $O/tests.log; exit 1; }
 tail -2 $O/tests.log
-python3 tools/odd_single.py 2>&1 | grep -v amdgpu > $O/odd_single.txt; cat $O/odd_single.txt
+for rep in 1 2; do python3 tools/narrow_rows.py 2>&1 | grep -v amdgpu; done > $O/rows.txt; cat $O/rows.txt
