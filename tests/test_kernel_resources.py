@@ -101,12 +101,12 @@ def test_pair_kernel_fits_one_workgroup_of_sixteen_waves(res):
 
 
 def test_narrow_kernels_hold_their_accumulator_sets_in_registers(res):
-    """voxelize_narrow_kernel (1 ... 8 channels, two or four sub-tiles per wave): compiled for 7 / 6 / 5 waves per SIMD so that
-    the NSUB accumulator sets and the eight row loads in flight stay in registers (at voxelize_kernel's 64 registers it
-    spilled up to 17)."""
+    """voxelize_narrow_kernel (1 ... 8 channels, two or four sub-tiles per wave): the NSUB accumulator sets and the eight row
+    loads in flight stay in registers, and since the staging became branch-free with one add per slot every variant fits the
+    64 registers of 8 waves per SIMD (it needed 66 ... 84 and was compiled for 7 / 6 / 5 before; profiles/r04_narrow.txt)."""
     ks = {k: v for k, v in res.items() if k.startswith("voxelize_narrow_kernel<")}
     assert len(ks) == 10  # {1, 4} channels x {2, 4} sub-tiles + 8 channels x 2, Gaussian and binary
     for name, r in ks.items():
-        assert r["vspill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 104, (name, r)
-    for gauss in ("true", "false"):
-        assert res[f"voxelize_narrow_kernel<1, {gauss}, 2>"]["vgpr"] <= 72 and res[f"voxelize_narrow_kernel<8, {gauss}, 2>"]["vgpr"] <= 80
+        assert r["vspill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 64, (name, r)
+
+
