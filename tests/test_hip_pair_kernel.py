@@ -4,7 +4,7 @@ The kernel replaces the body of one `forward()` call of the reference (numpy/vox
 float32 scan -> LDS stash -> float64 stage -> walk pipeline; every case below forces that route ("direct" test option), checks
 it against the CPU oracle on the same inputs (membership identical, Gaussian within tests/tolerance.py) and asserts that the
 binned pipeline gives the same BITS (both routes add the same float32 terms in atom order).
-Covered: survivors clustered in one wave's share (beyond the 48-entry stash: the trip back to memory; beyond 64 and 128 rows:
+Covered: survivors clustered in one wave's share (beyond the 48-entry stash: the trip back to memory; beyond 64 and 256 rows:
 several staging waves / rounds), odd atom counts at every block boundary (the molecule's last 16-byte chunk), molecules of
 several segments, the smallest grids (one or two waves per slab), per-type radii beyond the LDS table, ragged batches,
 transforms with a device-resident centre, degenerate radii.
@@ -42,11 +42,11 @@ def _check(out, ref, density):
         assert_gaussian(out, ref)
 
 
-@pytest.mark.parametrize("cluster", [40, 60, 100, 200, 400])
+@pytest.mark.parametrize("cluster", [40, 60, 100, 300, 600])
 @pytest.mark.parametrize("density", ["gaussian", "binary"])
 def test_survivors_clustered_in_one_waves_share(mv, cluster, density):
     """`cluster` consecutive atoms inside a 1.2 A ball (residue-like locality): one scanning wave finds them all - more than
-    its stash holds (48), more than one staging wave takes (64), more than a round of rows (128)."""
+    its stash holds (48), more than one staging wave takes (64), more than a round of rows (256, together with the other waves' finds)."""
     from oracle import c_oracle
 
     rng = np.random.default_rng(100 + cluster)
@@ -142,7 +142,7 @@ def test_ragged_batch_through_the_one_launch_route(mv):
     rng = np.random.default_rng(77)
     D, C_ = 16, 6
     W_ = 0.5 * (D - 1)
-    sizes = [0, 1, 33, 128, 129, 2500, 0, 64]
+    sizes = [0, 1, 33, 256, 257, 2500, 0, 64]  # (256 rows per round at D = 16: the no-scan limit)
     coords = [rng.uniform(-W_ / 2 - 0.5, W_ / 2 + 0.5, (n, 3)) for n in sizes]
     feats = [rng.random((n, C_)).astype(np.float32) for n in sizes]
     centers = rng.uniform(-0.4, 0.4, (len(sizes), 3))
@@ -216,3 +216,32 @@ def test_degenerate_atom_wise_radii(mv):
     assert torch.equal(outs[0], clean)
     # the huge radius reaches every voxel: channel sums are at least that atom's features everywhere
     assert (outs[0].cpu().numpy().reshape(3, -1).min(axis=1) >= feats[11] - 1e-6).all()
+
+
+def test_batch_with_a_random_transform_per_molecule(mv):
+    """forward_batch draws one transform per molecule, in molecule order (the loop of test/test_time_numpy.py:11-15 as one
+    call): both routes give the same bits, and the same bits as per-molecule forward() calls that consume the RNG alike."""
+    import torch
+
+    rng = np.random.default_rng(4242)
+    D, C_ = 24, 12
+    W_ = 0.5 * (D - 1)
+    sizes = [200, 0, 33, 1500, 129]
+    coords = [rng.uniform(-W_ / 2, W_ / 2, (n, 3)) + 7.0 for n in sizes]
+    feats = [rng.random((n, C_)).astype(np.float32) for n in sizes]
+    centers = np.full((len(sizes), 3), 7.0) + rng.uniform(-0.3, 0.3, (len(sizes), 3))
+    offsets = np.cumsum([0] + sizes)
+    v = mv.create_voxelizer(0.5, D, "scalar", "gaussian", "hip", sigma=0.5)
+    d_xyz, d_f = v.asarray(np.concatenate(coords), "coords"), v.asarray(np.concatenate(feats), "features")
+    d_cen = v.asarray(centers, "center")
+    outs = []
+    for route in (1, 0):
+        v.debug_option("direct", route)
+        np.random.seed(99)
+        outs.append(v.forward_batch(d_xyz, offsets, d_cen, d_f, 1.1, random_translation=0.5, random_rotation=True).clone())
+    v.debug_option("direct", -1)
+    assert torch.equal(outs[0], outs[1])
+    np.random.seed(99)
+    for b, n in enumerate(sizes):
+        one = v.forward(v.asarray(coords[b], "coords"), v.asarray(centers[b], "center"), v.asarray(feats[b], "features"), 1.1, 0.5, True)
+        assert torch.equal(one, outs[0][b]), b
