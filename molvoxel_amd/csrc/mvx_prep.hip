@@ -221,14 +221,16 @@ hipError_t launch_transform(const double *coords, int64_t N, const mvx_xform *xf
 // blocks per x-slab) or, for small batches, NQ = 4 (one block per (molecule, x-slab)).
 template <int THREADS, int XLN, int CH, int NQ>
 __global__ void __launch_bounds__(THREADS)
-    xbin_kernel(const uint2 *__restrict__ xp, const int64_t *__restrict__ offsets, int64_t n_one, int b0, int nsx, int nsy, int nzc, int NW,
-                uint2 *__restrict__ xlist, uint2 *__restrict__ slist, uint2 *__restrict__ slist_ext) {
+    xbin_kernel(const uint2 *__restrict__ xp, const int64_t *__restrict__ offsets, int64_t n_one, int b0, int nsx, unsigned nsx_inv, int nsy, int nzc,
+                int NW, uint2 *__restrict__ xlist, uint2 *__restrict__ slist, uint2 *__restrict__ slist_ext) {
     __shared__ uint2 xs[XLN]; // (one-wave blocks serve molecules of <= 256 atoms: XLN = 256)
     constexpr int NWV = THREADS / 64; // waves per block
     __shared__ int wcnt[2][NWV];
     __shared__ int any_overflow;
     __shared__ uint2 line[NWV][NQ * SLOTS]; // the NQ slab lines each wave is building
-    const int b = b0 + blockIdx.x / nsx, sx = blockIdx.x % nsx;
+    // (blockIdx.x = (molecule - b0) * nsx + sx, split without the run-time integer division: nsx_inv = ceil(2^32 / nsx))
+    const unsigned bq = nsx == 1 ? blockIdx.x : __umulhi(blockIdx.x, nsx_inv);
+    const int b = b0 + (int)bq, sx = (int)(blockIdx.x - bq * (unsigned)nsx);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t a0 = offsets ? offsets[b] : 0, a1 = offsets ? offsets[b + 1] : n_one; // (null: one molecule of n_one atoms)
     const int x0 = SUBX * sx;
@@ -325,8 +327,9 @@ __global__ void __launch_bounds__(THREADS)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int sl = g + q;
-            sy[q] = (sl < nslab) ? sl / nzc : 255; // 255: beyond the grid, matches no entry
-            zt_lo[q] = (sl - (sl / nzc) * nzc) * NW;
+            const int sq = nzc == 1 ? sl : sl / nzc; // (one slab per row - every grid of up to 64 voxels: no division)
+            sy[q] = (sl < nslab) ? sq : 255; // 255: beyond the grid, matches no entry
+            zt_lo[q] = (sl - sq * nzc) * NW;
             zt_hi[q] = zt_lo[q] + NW - 1;
             n[q] = 0;
         }
@@ -426,11 +429,12 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
                        int32_t nzc, int32_t NW, uint2 *xlist, uint2 *slist, uint2 *slist_ext, hipStream_t s) {
     if (nb <= 0) return hipSuccess;
     const int nslab = nsy * nzc;
+    const unsigned nsx_inv = nsx > 1 ? (unsigned)((0x100000000ull + (unsigned long long)nsx - 1) / (unsigned long long)nsx) : 0u;
     if (max_atoms <= 256) { // small molecules (one round of pass A for a single wave): one-wave blocks
         int parts = 1;
         while (parts * 4 < nslab && parts < 4 && (long long)nb * nsx * parts < 8192) parts *= 2;
         hipLaunchKernelGGL((xbin_kernel<64, 256, 4, 4>), dim3((unsigned)(nb * nsx), (unsigned)parts), dim3(64), 0, s, xp, offsets, n_one, b0, nsx,
-                           nsy, nzc, NW, xlist, slist, slist_ext);
+                           nsx_inv, nsy, nzc, NW, xlist, slist, slist_ext);
         return hipGetLastError();
     }
     // one block builds 16 slab lines per pass; grids with more slabs per x-slab (D > 64) and few molecules get
@@ -450,10 +454,10 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
 #define MVX_XBIN_BIG(CHUNKS)                                                                                                          \
     do {                                                                                                                              \
         if (four)                                                                                                                     \
-            hipLaunchKernelGGL((xbin_kernel<1024, 2 * XL_LDS, CHUNKS, 4>), grid, dim3(1024), 0, s, xp, offsets, n_one, b0, nsx, nsy, nzc, \
+            hipLaunchKernelGGL((xbin_kernel<1024, 2 * XL_LDS, CHUNKS, 4>), grid, dim3(1024), 0, s, xp, offsets, n_one, b0, nsx, nsx_inv, nsy, nzc, \
                                NW, xlist, slist, slist_ext);                                                                          \
         else                                                                                                                          \
-            hipLaunchKernelGGL((xbin_kernel<1024, 4 * XL_LDS, CHUNKS, 1>), grid, dim3(1024), 0, s, xp, offsets, n_one, b0, nsx, nsy, nzc, \
+            hipLaunchKernelGGL((xbin_kernel<1024, 4 * XL_LDS, CHUNKS, 1>), grid, dim3(1024), 0, s, xp, offsets, n_one, b0, nsx, nsx_inv, nsy, nzc, \
                                NW, xlist, slist, slist_ext);                                                                          \
     } while (0)
             if (max_atoms <= 4 * 1024) MVX_XBIN_BIG(4); // all of the largest molecule's atoms in flight at once when <= 16 384
@@ -470,7 +474,7 @@ hipError_t launch_xbin(const uint2 *xp, const int64_t *offsets, int64_t n_one, i
     // (cfg-2, 256 molecules: 56.4 us with 4 chunks = four rounds, 50.7 with 8, 48.6 with 16)
     const dim3 grid((unsigned)(nb * nsx), (unsigned)parts);
 #define MVX_XBIN_256(CHUNKS)                                                                                                          \
-    hipLaunchKernelGGL((xbin_kernel<256, XL_LDS, CHUNKS, 4>), grid, dim3(256), 0, s, xp, offsets, n_one, b0, nsx, nsy, nzc, NW, xlist, \
+    hipLaunchKernelGGL((xbin_kernel<256, XL_LDS, CHUNKS, 4>), grid, dim3(256), 0, s, xp, offsets, n_one, b0, nsx, nsx_inv, nsy, nzc, NW, xlist, \
                        slist, slist_ext)
     if (max_atoms <= 1024) MVX_XBIN_256(4);
     else if (max_atoms <= 2048) MVX_XBIN_256(8);
