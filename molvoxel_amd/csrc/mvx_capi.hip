@@ -526,6 +526,8 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.ncc = ncc;
     va.p.nsy_inv = umulhi_inverse(plan.nsy);
     va.p.nzc_inv = umulhi_inverse(plan.nzc);
+    va.p.nsx_inv = umulhi_inverse(plan.nsx);
+    va.p.ncc_inv = umulhi_inverse(ncc);
     va.p.b0 = 0;
     va.p.c0 = 0;
     va.p.NW = plan.nw;

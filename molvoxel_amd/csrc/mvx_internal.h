@@ -80,6 +80,7 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
     int32_t D, C, B;
     int32_t nsx, nsy, nzc, ncc; // slabs along x, along y, z chunks, channel chunks
     uint32_t nsy_inv, nzc_inv; // ceil(2^32 / d): n / d == __umulhi(n, inv) for the slab ids used here (n * d < 2^32)
+    uint32_t nsx_inv, ncc_inv; // ... the same for nsx (slabs in x-fastest order, grids of several slabs per row) and the channel chunks
     int32_t b0;            // first molecule of this launch (blockIdx.y = (molecule - b0) * ncc + channel chunk)
     int32_t c0;            // first channel of this launch's chunks (voxelize_kernel: a remainder launch with a narrower kernel)
     int32_t NW;            // waves per workgroup = 4^3 sub-tiles per slab

@@ -95,11 +95,12 @@ __global__ void __launch_bounds__(512, narrow_waves_per_simd(CT, NSUB))
     unsigned t = blockIdx.x;
     if (P.nzc > 1) { // consecutive blocks = consecutive x-slabs (mvx_slab_body.inc)
         const unsigned per_x = (unsigned)(P.nsy * P.nzc), nsx = (unsigned)P.nsx;
-        t = (t % nsx) * per_x + t / nsx;
+        const unsigned tq = __umulhi(t, P.nsx_inv); // t / nsx (nsx > 1 here: several slabs per row means D > 64)
+        t = (t - tq * nsx) * per_x + tq;
     }
     int b = (int)blockIdx.y, cc = 0;
     if (P.ncc > 1) {
-        b = (int)blockIdx.y / P.ncc;
+        b = (int)__umulhi(blockIdx.y, P.ncc_inv); // blockIdx.y / ncc
         cc = (int)blockIdx.y - b * P.ncc;
     }
     b += P.b0;
