@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(MAXT, DIRECT_WAVES_PER_SIMD)
     const unsigned t = blockIdx.x;
     int b = (int)blockIdx.y, cc = 0;
     if (P.ncc > 1) {
-        b = (int)blockIdx.y / P.ncc;
+        b = (int)__umulhi(blockIdx.y, P.ncc_inv); // blockIdx.y / ncc
         cc = (int)blockIdx.y - b * P.ncc;
     }
     int sx, sy, zc;

@@ -42,7 +42,8 @@ constexpr int PAIR_SEGW_MIN = PAIR_BLOCK * PAIR_MAX_BLOCKS; // atoms per wave an
 constexpr int PAIR_SEGW_MAX = 2048;                         // 16 waves) ... 2 048 (32 768 atoms), chosen at launch (VoxParams::dcap)
 constexpr int PAIR_ROWS = 256;                            // candidate rows staged per round (both slabs share them), 64 per staging wave:
                                                           // a pair of slabs at cfg-2's density holds ~62 candidates at radius 1 A, ~140 at 2 A;
-                                                          // more than a round's rows means further, cold rounds (12 000 atoms at 64^3: 25 -> 28 us)
+                                                          // more than a round's rows means further, slower rounds (with 128 rows per round a
+                                                          // molecule of 12 000 atoms took 27.9 us, with 256 23.0)
 constexpr int PAIR_STASH = 48;                            // survivors per wave and segment whose float64 position, radius and type stay in LDS
 constexpr int PAIR_RTAB = 256;                            // per-type radii kept in LDS (forward_types with channel-wise radii)
 struct __attribute__((aligned(16))) PairStash {           // what the scan already held about a survivor: no second trip to memory
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
     typedef typename PairOps<CT, GAUSS>::type Ops;
     constexpr int SW = Ops::SW;
     constexpr int WW = Ops::WW; // weight words per row
-    // blocks of 128 atoms a wave fetches at once: four (48 registers of coordinates in flight), two where the transform's
+    // blocks of 128 atoms a wave fetches at once: four (48 registers of coordinates in flight), three where the transform's
     // constants share the register file (with four the scan of the transform variants kept a dozen registers in scratch:
     // the reference's timing loop 12.4 -> 15.1 us per call)
     constexpr int HOTB = XF ? 3 : PAIR_MAX_BLOCKS;
@@ -122,8 +123,8 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
     PairStash *stash = stash_all + wave * PAIR_STASH; // ... and what the scan knew about the first PAIR_STASH of them
 
     int b = (int)blockIdx.y, cc = 0;
-    if (P.ncc > 1) {
-        b = (int)blockIdx.y / P.ncc;
+    if (P.ncc > 1) { // (channel chunks - C > 32 - are separate workgroups: an in-kernel loop cost more than it shared, see above)
+        b = (int)__umulhi(blockIdx.y, P.ncc_inv); // blockIdx.y / ncc
         cc = (int)blockIdx.y - b * P.ncc;
     }
     int px, sy, zc;
