@@ -136,3 +136,18 @@ def test_pacing_guard_rows_are_recorded(record_property):
         print(f'{r["config"]}: kernel {r["kernel_ms"]:.3f} ms = {r["of_peak"]:.3f} of peak')
     by = {r["config"]: r["of_peak"] for r in rows}
     assert by["pacing guard: cfg2 x256"] > 0.6 and by["pacing guard: cfg2 x64"] > 0.55 and by["pacing guard: cfg4 ligands x128"] > 0.6
+
+
+def test_per_molecule_call_kernel_times_are_recorded(record_property):
+    """One molecule per forward() call (the reference's unit of work): records the launch's duration by HIP events for cfg-2 and
+    cfg-3 - voxelize_pair_kernel, 14 us and 7 us when this was written (20 us / 10 us with the kernel it replaced) - so that a
+    regression of the per-molecule path shows in the test report. Only a gross cliff fails it."""
+    import bench_configs
+    from molvoxel_amd import workloads as W
+
+    rows = [bench_configs.run("cfg2 single call", W.cfg2(), [0], steps=60, warmup=30),
+            bench_configs.run("cfg3 single call", W.cfg3(), [0], steps=60, warmup=30)]
+    for r in rows:
+        record_property(r["config"], round(1e3 * r["kernel_ms"], 1))
+        print(f'{r["config"]}: kernel {1e3 * r["kernel_ms"]:.1f} us, call {1e3 * r["ms_per_call"]:.1f} us')
+    assert rows[0]["kernel_ms"] < 0.030 and rows[1]["kernel_ms"] < 0.020
