@@ -20,14 +20,12 @@ namespace mvx {
 //      the atom's radius window, widened by the float32 error bound (SCAN_MARGIN), is tested against the slab's box:
 //      a superset of the atoms that can reach the slab (the exact float64 decisions are step B's). Survivors are appended, by ballot + prefix, to the wave's region of an LDS
 //      list; one barrier. Regions in wave order = candidates IN ATOM ORDER (sums bit-identical to the binned path's).
-//   B. rounds of up to 64 candidates: lane u < 8 of wave w prepares slot w + u*NW - position, exact box cull and the
-//      cull of the reference blocks this slab lies in (x, y), threshold T, coefficient k - and writes the 64-B record
-//      straight into the LDS row, while the wave's other lanes fetch the slot's channel weights from the caller's
-//      feature rows (or build the one-hot / unit row of forward_types / forward_single); one barrier; every wave
-//      then selects, one lane per row, the rows that pass ITS sub-tile's z block cull and z window, and walks them
-//      (Ops::accumulate); write-out as everywhere (Ops::write).
-//      Sub-tiles that straddle reference blocks (LANE_RANGE: blockdim 4, 5, 12, ...) need per-lane voxel ranges:
-//      those variants run prep_atom per candidate instead, as the prep kernel does.
+//   B. rounds of up to 64 candidates: lane u < 8 of wave w prepares slot w + u*NW with prep_atom, as the prep kernel does
+//      (sub-tiles that straddle reference blocks - blockdim 4, 5, 12, ... - need per-lane voxel ranges), and writes the
+//      64-B record straight into the LDS row, while the wave's other lanes fetch the slot's channel weights from the
+//      caller's feature rows (or build the one-hot / unit row of forward_types / forward_single); one barrier; every
+//      wave then selects, one lane per row, the rows whose admitted z range reaches ITS sub-tile, and walks them
+//      (Ops::accumulate, per-lane range checks); write-out as everywhere (Ops::write).
 //   Any number of candidates and atoms works (rounds, segments); there is no overflow list and no dense kernel.
 // LDS map: u16 list[NW*512] | int wcnt[16] | u32 pk[64] | union { scan strips ; rows ; tile }.
 // (Channel-wise radii for features take the binned pipeline - the grouped matrix-core launch - whatever the call's size.)
@@ -44,6 +42,7 @@ static size_t direct_lds_bytes(int32_t ct, int32_t NW) {
 template <int CT, bool GAUSS, bool LANE_RANGE, int MAXT>
 __global__ void __launch_bounds__(MAXT, DIRECT_WAVES_PER_SIMD)
     voxelize_direct_kernel(const DirectArgs A, float *__restrict__ out, const VoxParams P) {
+    static_assert(LANE_RANGE, "only the per-lane-range instantiations are built (mvx_pair.hip serves uniform block culls)");
     typedef OpsF32<CT, GAUSS, LANE_RANGE> Ops;
     constexpr int SW = Ops::SW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -70,7 +69,6 @@ __global__ void __launch_bounds__(MAXT, DIRECT_WAVES_PER_SIMD)
     const int cbase = cc * CT; // first channel of this workgroup's chunk
     const PrepArgs &pa = A.pa;
     const int C = pa.C;
-    const Geom &g = pa.g;
 
     int64_t a0 = 0, a1 = A.N;
     if (pa.offsets) {
@@ -96,7 +94,6 @@ __global__ void __launch_bounds__(MAXT, DIRECT_WAVES_PER_SIMD)
     const float hx = uniform((float)(0.5 * (bx1 - bx0)) * 1.000001f + 1e-6f), hy = uniform((float)(0.5 * (by1 - by0)) * 1.000001f + 1e-6f),
                 hz = uniform((float)(0.5 * (bz1 - bz0)) * 1.000001f + 1e-6f);
 
-    const BlockBounds Bx = block_bounds(g, x0), By = block_bounds(g, y0); // the reference blocks this slab lies in
     const int RW = 8 * NW < 64 ? 8 * NW : 64; // candidate rows per round
     const int64_t SEGN = (int64_t)NW * SEGW;
     // a molecule that fits one round of rows (ligands) skips the scan: every atom is staged, and the stage's own
@@ -285,42 +282,6 @@ __global__ void __launch_bounds__(MAXT, DIRECT_WAVES_PER_SIMD)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dst[i] = src[i];
                 pk[sl] = keep ? (((unsigned)zlo << 16) | ((unsigned)zhi << 24)) : EMPTY_ENTRY;
-            } else {
-                // sub-tiles lie inside one reference block: the culls are uniform over this slab (x, y) and
-                // over each wave's sub-tile (z, tested by the waves below); same comparisons as prep_atom
-                const double ub = g.half, lb = -1 * g.half;
-                float r32;
-                double rc;
-                bool keep = true;
-                if (pa.types) {
-                    my_type = pa.types[a];
-                    if (my_type < 0 || my_type >= C) keep = false;
-                }
-                if (pa.radii_src == RAD_SCALAR) {
-                    rc = pa.radius_scalar;
-                    r32 = (float)pa.radius_scalar;
-                    for (int i = 0; i < 3; ++i) keep = keep && (p[i] > lb - rc) && (p[i] < ub + rc); // numpy/voxelizer.py:487-488
-                } else {
-                    const int64_t ri = (pa.radii_src == RAD_ATOM) ? a : (keep ? (int64_t)my_type : -1); // :284-285
-                    r32 = ri >= 0 ? static_cast<const float *>(pa.radii)[ri] : 0.0f;
-                    rc = (double)r32;
-                    for (int i = 0; i < 3; ++i) keep = keep && (p[i] + rc > lb) && (p[i] - rc < ub); // :491-492
-                }
-                // (one python float for every atom: threshold and coefficient come with the launch)
-                const double T = pa.radii_src == RAD_SCALAR ? pa.T_scalar : d2_threshold(r32);
-                keep = keep && (T >= 0.0);
-                keep = keep && block_admits(Bx, p[0], rc) && block_admits(By, p[1], rc);
-                const double rrd = (double)r32 * 1.000001 + 1e-9; // conservative window, as prep_atom's
-                keep = keep && (p[0] + rrd >= bx0) && (p[0] - rrd <= bx1) && (p[1] + rrd >= by0) && (p[1] - rrd <= by1);
-                typedef double d2v __attribute__((ext_vector_type(2)));
-                d2v *dst = reinterpret_cast<d2v *>(un + sl * SW);
-                dst[0] = (d2v){p[0], p[1]};
-                dst[1] = (d2v){p[2], T};
-                un[sl * SW + 8] = __float_as_uint(!GAUSS ? 0.0f : (pa.radii_src == RAD_SCALAR ? pa.k_scalar : gauss_coeff(r32, pa.sigma32)));
-                un[sl * SW + 9] = (unsigned)my_type;
-                *reinterpret_cast<double *>(un + sl * SW + 10) = rc;
-                // z window radius, rounded up to float; a dropped candidate gets a negative one
-                un[sl * SW + 12] = __float_as_uint(keep ? (float)rrd * 1.0000002f : -1.0f);
             }
         }
     }
@@ -365,17 +326,6 @@ __global__ void __launch_bounds__(MAXT, DIRECT_WAVES_PER_SIMD)
                 const unsigned pkl = pk[lane];
                 kept = pkl != EMPTY_ENTRY;
                 ok = ((int)((pkl >> 16) & 0xff) <= zt_lo + wave) && ((int)(pkl >> 24) >= zt_lo + wave);
-            } else {
-                const unsigned *r = un + lane * SW;
-                const double pz = *reinterpret_cast<const double *>(r + 4);
-                const double rc = *reinterpret_cast<const double *>(r + 10);
-                const double rr = (double)__uint_as_float(r[12]);
-                const int zv = z0 + SUBZ * wave; // first voxel of this wave's sub-tile
-                const int zl = (zv + SUBZ - 1 < P.D - 1) ? zv + SUBZ - 1 : P.D - 1;
-                const BlockBounds Bz = block_bounds(g, zv);
-                kept = (rr >= 0.0) && (pz + rr >= bz0) && (pz - rr <= bz1);
-                ok = kept && (zv < P.D) && block_admits(Bz, pz, rc) &&
-                     (pz + rr >= (double)zv * P.res - P.half - slack) && (pz - rr <= (double)zl * P.res - P.half + slack);
             }
         }
         any = any || __ballot(kept) != 0ull; // (the same rows in every wave: workgroup-uniform)
