@@ -227,7 +227,7 @@ int mvx_debug_set_option(mvx_handle *h, const char *name, int32_t value);
  */
 enum mvx_route {
     MVX_ROUTE_BINNED = 0,    /* prep -> xbin -> voxelize_kernel (slab lines; the batched float32 pipeline) */
-    MVX_ROUTE_DIRECT = 1,    /* voxelize_pair_kernel (voxelize_direct_kernel for per-lane ranges / run-wise grids): the whole call in one launch */
+    MVX_ROUTE_DIRECT = 1,    /* voxelize_pair_kernel: the whole call in one launch */
     MVX_ROUTE_F64_DENSE = 2, /* float64 grids, general slab loop */
     MVX_ROUTE_F64_MX = 3     /* float64 grids, 32-channel chunks on the matrix cores */
 };

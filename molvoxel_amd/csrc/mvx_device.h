@@ -1,5 +1,5 @@
 // mvx_device.h - device-side building blocks shared by the kernel translation units (mvx_prep.hip, mvx_slab.hip,
-// mvx_direct.hip, mvx_f64.hip): exact arithmetic of the membership rule, the rigid transform, per-atom preparation
+// mvx_pair.hip, mvx_f64.hip): exact arithmetic of the membership rule, the rigid transform, per-atom preparation
 // (culls -> admitted voxel ranges), the one-voxel-per-lane accumulator set (OpsF32) with its write-out paths, and the
 // staging / filter / walk steps of a slab round (used through mvx_slab_body.inc).
 //
@@ -145,7 +145,7 @@ __device__ inline void apply_xform(const mvx_xform &xf, double &x, double &y, do
     }
 }
 
-// The same transform in float32, for the direct kernel's candidate scan only: a cheap estimate of where the atom lands,
+// The same transform in float32, for the per-molecule kernel's candidate scan only: a cheap estimate of where the atom lands,
 // p' = M (p - c) + o with M the matrix of q p conj(q) (identity without a rotation). Every float32 operation is off by
 // at most 2^-24 of its result and all intermediates are bounded by s (|p|_1 + |c|_1) + |o|_1, s = max(1, |q|^2), on
 // paths a handful of operations deep: the estimate is within ~1e-6 of that magnitude of the float64 result. The scan
@@ -260,7 +260,7 @@ constexpr uint32_t EMPTY_ENTRY = 0x00ff00ffu; // packed y/z slab ranges: y lo = 
 
 // Everything the path knows about one atom once its position p (after centring / transform) is fixed: the culls of
 // rule steps 1-2 folded into admitted voxel ranges, the membership threshold T, the gaussian coefficient k. Shared by
-// prep_kernel (one thread per atom, records to memory) and voxelize_direct_kernel (one lane per candidate, records
+// prep_kernel (one thread per atom, records to memory) and voxelize_pair_kernel's per-lane-range stage (one lane per candidate, records
 // straight into LDS). rmax32 / rmax64: max channel radius (RAD_CHANNEL_FEATURES only). Returns false when no voxel
 // can receive a contribution (ranges then are EMPTY_RANGE).
 __device__ __forceinline__ bool prep_atom(const PrepArgs &A, int64_t a, const double (&p)[3], float rmax32, double rmax64,
@@ -374,7 +374,7 @@ __device__ __forceinline__ bool prep_atom(const PrepArgs &A, int64_t a, const do
     return keep;
 }
 
-// ---- per-molecule kernels (mvx_direct.hip, mvx_pair.hip): block cull of ONE reference block, uniform over a slab ----
+// ---- per-molecule kernel (mvx_pair.hip): block cull of ONE reference block, uniform over a slab ----
 // reference block cull along one axis for the block holding voxel index v (numpy/voxelizer.py:500-513):
 // lo / hi are bounds[b-1] and bounds[b] (numpy/voxelizer.py:55), has_lo / has_hi say whether the comparison applies
 struct BlockBounds {
@@ -749,8 +749,8 @@ __device__ __forceinline__ LaneCtx make_lane_ctx(int lane, int wave, int x0, int
 
 // An "Ops" type is what differs between the accumulator layouts of the slab kernels: accumulator type, staged row width,
 // the per-candidate update and the write-out. OpsF32: one voxel per lane, CT float32 channels per lane on the vector ALU
-// (chunks of fewer than 32 channels, per-lane-range variants, the per-molecule direct kernel); OpsMx32 (mvx_slab.hip): 32
-// channels on the matrix cores; OpsF64 / OpsMx64 (mvx_f64.hip): float64 grids.
+// (chunks of fewer than 32 channels, per-lane-range variants); OpsMx32 / OpsPair (mvx_ops32.h): 32 channels on the
+// matrix cores / candidate pairs on the vector ALU; OpsF64 / OpsMx64 (mvx_f64.hip): float64 grids.
 template <int CT_, bool GAUSS, bool LANE_RANGE>
 struct OpsF32 {
     static constexpr bool RUNS = LANE_RANGE; // carries the run-wise write-out (store_runs)
@@ -786,14 +786,6 @@ struct OpsF32 {
                                                  int b, const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
         write_slab<CT, LANE_RANGE>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
                        static_cast<float *>(out), P);
-    }
-    // per-molecule launches (voxelize_direct_kernel): 16 channels per round - two rounds, four barriers; the small
-    // rounds pay when thousands of workgroups' store bursts interleave, not when 512 workgroups store once (cfg-2
-    // single call 21.2 -> 20.4 us)
-    static __device__ __forceinline__ void write_wide(const Acc &acc, bool any, unsigned *un, int tid, int lane, int wave, int NW,
-                                                      int b, const LaneCtx &L, int x0, int y0, int z0, void *out, const VoxParams &P) {
-        write_slab<CT, LANE_RANGE, DIRECT_CR>(acc, any, reinterpret_cast<float *>(un), tid, lane, wave, NW, b, L.cbase, x0, y0, z0,
-                                  static_cast<float *>(out), P);
     }
 };
 

@@ -91,11 +91,11 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
     int32_t xcd_ranges;    // 1: every XCD takes a contiguous range of slabs (run-wise write-out of whole-row slabs; gridDim.x = 8 ceil(T / 8))
     double sigma;          // float64 grids: the Gaussian sigma as the reference holds it (python float)
 #ifdef MVX_DIAG
-    int32_t dbg;           // diagnostic builds: run-time ablation switches of voxelize_direct_kernel
+    int32_t dbg;           // diagnostic builds: run-time ablation switches of voxelize_pair_kernel
 #endif
 };
 
-// voxelize_direct_kernel: the atoms as the caller passed them (PrepArgs without workspace pointers) plus, for a
+// voxelize_pair_kernel: the atoms as the caller passed them (PrepArgs without workspace pointers) plus, for a
 // single molecule, its extent and transform by value (no metadata upload).
 struct DirectArgs {
     PrepArgs pa;   // rec / wbuf / xp / chan_aux unused; offsets / xforms: device arrays, or null for one molecule
@@ -133,7 +133,7 @@ struct VoxArgs {
     VoxParams p;
 };
 
-// launchers (host side: mvx_prep.hip, mvx_slab.hip, mvx_direct.hip, mvx_f64.hip)
+// launchers (host side: mvx_prep.hip, mvx_slab.hip, mvx_pair.hip, mvx_f64.hip)
 // chan_slot: C ints, the slot of every channel (grouped launch)
 hipError_t launch_chan_aux(const float *radii, int32_t C, int32_t density, float sigma32, float *rmax, ChanGroups *groups,
                            int32_t *chan_slot, hipStream_t s);
@@ -153,12 +153,10 @@ hipError_t launch_voxelize(const VoxArgs &a, int32_t nb, int32_t ct, bool gauss,
 hipError_t launch_voxelize_grouped(const VoxArgs &a, int32_t nb, bool gauss, bool lane_range, hipStream_t s);
 // float64 grids: every slab of the whole batch through the general slab loop (ct <= 16; a.p.dcap must be 64)
 hipError_t launch_voxelize64(const VoxArgs &a, int32_t ct, bool gauss, bool chanwise, bool lane_range, hipStream_t s);
-// the whole call in one launch (float32 grids, NW <= 8): no workspace, no pre-pass
+// the whole call in one launch (voxelize_pair_kernel, mvx_pair.hip: float32 grids, NW <= 8): no workspace, no pre-pass.
+// max_atoms: the largest molecule of the call (sizes the per-wave candidate lists); lane_range: sub-tiles cut by reference blocks
 hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, int64_t max_atoms, float *out, int32_t ct, bool gauss,
                                   bool lane_range, hipStream_t s);
-// ... the same call with two slabs per workgroup sharing one atom scan (mvx_pair.hip): aligned grids, uniform block culls
-// (max_atoms: the largest molecule of the call - sizes the per-wave candidate lists)
-hipError_t launch_voxelize_pair(const DirectArgs &d, const VoxParams &p, int64_t max_atoms, float *out, int32_t ct, bool gauss, hipStream_t s);
 void scalar_radius_constants(double radius_scalar, float sigma32, bool gauss, double *T, float *k);
 // profiled launches: the next voxelize launch on this thread carries these events on its own dispatch packet
 void set_launch_events(hipEvent_t start, hipEvent_t stop);

@@ -3,8 +3,8 @@
 // The reference's unit of work is one molecule per forward() call (test/test_time_numpy.py:11-15; Voxelizer.forward_features /
 // forward_types / forward_single, numpy/voxelizer.py:97-169, 240-315, 370-436). Such a call is a chain of latencies, not
 // work: launch -> coordinates -> which atoms reach this slab -> their records and weights -> walk -> stores, in front of
-// ~5.5 us of HBM drain for a cfg-2 grid. This kernel replaces voxelize_direct_kernel (mvx_direct.hip, kept for the
-// per-lane-range / run-wise variants) on that path: cfg-2 call 20.5 -> 14.9 us, the reference's timing loop 17.9 -> 12.9
+// ~5.5 us of HBM drain for a cfg-2 grid. This kernel replaced the round-2 voxelize_direct_kernel (one slab per
+// workgroup, every wave scanning for itself) on that path: cfg-2 call 20.5 -> 14.9 us, the reference's timing loop 17.9 -> 12.9
 // (profiles/r04_single_calls.txt). What the old kernel's phase timeline showed (tools/direct_timeline.py, cfg-2: scan 12.0 of
 // a workgroup's 25.6 kcycles, 21 of 27 on the reference's own timing loop) and the rules this one is built on:
 //   * Sixteen waves run the front side by side on one compute unit, so every instruction of it costs ~16 cycles of the call:
@@ -55,13 +55,23 @@ static_assert(sizeof(PairStash) == 32, "two 16-byte LDS writes per survivor");
 
 // (the write-outs carry the run-wise path - store_runs - beside the 16-byte one: grids whose rows are not whole quads, odd
 // dimensions and unaligned slices of a batch grid, take this kernel too)
-template <int CT, bool GAUSS>
+// LR: blockdims whose reference blocks cut through sub-tiles (4, 5, 12, ...) - every lane checks its voxel's index against the
+// atom's admitted ranges (prep_atom's block_interval), one voxel per lane and candidate (OpsF32 / OpsMx32 with per-lane ranges)
+template <int CT, bool GAUSS, bool LR>
 struct PairOps {
     typedef OpsPair<CT, GAUSS, true> type;
 };
 template <bool GAUSS>
-struct PairOps<32, GAUSS> {
+struct PairOps<32, GAUSS, false> {
     typedef OpsMx32<GAUSS, false, false, true> type;
+};
+template <int CT, bool GAUSS>
+struct PairOps<CT, GAUSS, true> {
+    typedef OpsF32<CT, GAUSS, true> type;
+};
+template <bool GAUSS>
+struct PairOps<32, GAUSS, true> {
+    typedef OpsMx32<GAUSS, true, false, true> type;
 };
 
 __host__ __device__ inline int pair_tile_words(int ct, int NW) { // one slab's write-out tile (Ops::write)
@@ -97,9 +107,9 @@ __device__ __forceinline__ int row_prefix16(int v) {
     return v;
 }
 
-template <int CT, bool GAUSS, bool XF>
+template <int CT, bool GAUSS, bool XF, bool LR = false>
 __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A, float *__restrict__ out, const VoxParams P) {
-    typedef typename PairOps<CT, GAUSS>::type Ops;
+    typedef typename PairOps<CT, GAUSS, LR>::type Ops;
     constexpr int SW = Ops::SW;
     constexpr int WW = Ops::WW; // weight words per row
     // blocks of 128 atoms a wave fetches at once: four (48 registers of coordinates in flight), three where the transform's
@@ -410,36 +420,52 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
                 if (p[0] != 1.2345e300) MVX_STAMP(7); // (after the coordinates have arrived)
 #endif
                 if constexpr (XF) apply_xform(xf, p[0], p[1], p[2]);
-                const double ub = g.half, lb = -1 * g.half;
-                if (pa.radii_src == RAD_SCALAR) {
-                    for (int q = 0; q < 3; ++q) keep = keep && (p[q] > lb - rc) && (p[q] < ub + rc); // numpy/voxelizer.py:487-488
+                if constexpr (LR) {
+                    // per-lane voxel ranges are needed: the prep kernel's own code for the whole record (it fetches type and
+                    // radius itself), the pair's box against the admitted ranges
+                    AtomRec R;
+                    uint32_t rng[3];
+                    bool keepr = prep_atom(pa, a0 + (int64_t)arel, p, 0.0f, 0.0, R, rng);
+                    my_type = R.type;
+                    keepr = keepr && ((int)(rng[0] & 0xffff) <= x0p + 2 * SUBX - 1) && ((int)(rng[0] >> 16) >= x0p) &&
+                            ((int)(rng[1] & 0xffff) <= y0 + SUBY - 1) && ((int)(rng[1] >> 16) >= y0);
+                    if (!keepr) R.xr = R.yr = R.zr = EMPTY_RANGE;
+                    const uint4 *src = reinterpret_cast<const uint4 *>(&R);
+                    uint4 *dst = reinterpret_cast<uint4 *>(row);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) dst[q4] = src[q4];
                 } else {
-                    for (int q = 0; q < 3; ++q) keep = keep && (p[q] + rc > lb) && (p[q] - rc < ub); // :491-492
+                    const double ub = g.half, lb = -1 * g.half;
+                    if (pa.radii_src == RAD_SCALAR) {
+                        for (int q = 0; q < 3; ++q) keep = keep && (p[q] > lb - rc) && (p[q] < ub + rc); // numpy/voxelizer.py:487-488
+                    } else {
+                        for (int q = 0; q < 3; ++q) keep = keep && (p[q] + rc > lb) && (p[q] - rc < ub); // :491-492
+                    }
+                    // (one python float for every atom: threshold and coefficient come with the launch)
+                    const double T = pa.radii_src == RAD_SCALAR ? pa.T_scalar : d2_threshold(r32);
+                    keep = keep && (T >= 0.0);
+                    // sub-tiles lie inside one reference block: the x / y block culls are uniform over the pair (its 4 x 4 voxels
+                    // share a block: blockdim is a multiple of 8 here), the z cull over each wave's sub-tile (walk)
+                    const BlockBounds Bx = block_bounds_lane(g, x0p), By = block_bounds_lane(g, y0);
+                    keep = keep && block_admits(Bx, p[0], rc) && block_admits(By, p[1], rc);
+                    // the pair's box (voxel centres), widened by the atom's radius window (conservative, as prep_atom's)
+                    const double slack = 1e-6 * P.res;
+                    const double bx0 = (double)x0p * P.res - P.half - slack, bx1 = (double)(x0p + 2 * SUBX - 1) * P.res - P.half + slack;
+                    const double by0 = (double)y0 * P.res - P.half - slack, by1 = (double)(y0 + SUBY - 1) * P.res - P.half + slack;
+                    const double bz0 = -P.half - slack, bz1 = (double)(D - 1) * P.res - P.half + slack;
+                    const double rrd = (double)r32 * 1.000001 + 1e-9;
+                    keep = keep && (p[0] + rrd >= bx0) && (p[0] - rrd <= bx1) && (p[1] + rrd >= by0) && (p[1] - rrd <= by1) &&
+                           (p[2] + rrd >= bz0) && (p[2] - rrd <= bz1);
+                    typedef double d2v __attribute__((ext_vector_type(2)));
+                    d2v *dst = reinterpret_cast<d2v *>(row);
+                    dst[0] = (d2v){p[0], p[1]};
+                    dst[1] = (d2v){p[2], T};
+                    row[8] = __float_as_uint(!GAUSS ? 0.0f : (pa.radii_src == RAD_SCALAR ? pa.k_scalar : gauss_coeff(r32, pa.sigma32)));
+                    row[9] = (unsigned)my_type;
+                    *reinterpret_cast<double *>(row + 10) = rc;
+                    // window radius, rounded up to float; a dropped candidate gets a negative one
+                    row[12] = __float_as_uint(keep ? (float)rrd * 1.0000002f : -1.0f);
                 }
-                // (one python float for every atom: threshold and coefficient come with the launch)
-                const double T = pa.radii_src == RAD_SCALAR ? pa.T_scalar : d2_threshold(r32);
-                keep = keep && (T >= 0.0);
-                // sub-tiles lie inside one reference block: the x / y block culls are uniform over the pair (its 4 x 4 voxels
-                // share a block: blockdim is a multiple of 8 here), the z cull over each wave's sub-tile (walk)
-                const BlockBounds Bx = block_bounds_lane(g, x0p), By = block_bounds_lane(g, y0);
-                keep = keep && block_admits(Bx, p[0], rc) && block_admits(By, p[1], rc);
-                // the pair's box (voxel centres), widened by the atom's radius window (conservative, as prep_atom's)
-                const double slack = 1e-6 * P.res;
-                const double bx0 = (double)x0p * P.res - P.half - slack, bx1 = (double)(x0p + 2 * SUBX - 1) * P.res - P.half + slack;
-                const double by0 = (double)y0 * P.res - P.half - slack, by1 = (double)(y0 + SUBY - 1) * P.res - P.half + slack;
-                const double bz0 = -P.half - slack, bz1 = (double)(D - 1) * P.res - P.half + slack;
-                const double rrd = (double)r32 * 1.000001 + 1e-9;
-                keep = keep && (p[0] + rrd >= bx0) && (p[0] - rrd <= bx1) && (p[1] + rrd >= by0) && (p[1] - rrd <= by1) &&
-                       (p[2] + rrd >= bz0) && (p[2] - rrd <= bz1);
-                typedef double d2v __attribute__((ext_vector_type(2)));
-                d2v *dst = reinterpret_cast<d2v *>(row);
-                dst[0] = (d2v){p[0], p[1]};
-                dst[1] = (d2v){p[2], T};
-                row[8] = __float_as_uint(!GAUSS ? 0.0f : (pa.radii_src == RAD_SCALAR ? pa.k_scalar : gauss_coeff(r32, pa.sigma32)));
-                row[9] = (unsigned)my_type;
-                *reinterpret_cast<double *>(row + 10) = rc;
-                // window radius, rounded up to float; a dropped candidate gets a negative one
-                row[12] = __float_as_uint(keep ? (float)rrd * 1.0000002f : -1.0f);
                 if (own_row) {
 #pragma unroll
                     for (int qd = 0; qd < CT / 4; ++qd) *reinterpret_cast<f4a16 *>(row + 16 + 4 * qd) = wq[qd];
@@ -505,15 +531,23 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
                 const int rw = 64 * half + lane;
                 if (rw < n) {
                     const unsigned *r = un + (size_t)rw * SW;
-                    const double pxr = *reinterpret_cast<const double *>(r);
-                    const double pz = *reinterpret_cast<const double *>(r + 4);
-                    const double rc = *reinterpret_cast<const double *>(r + 10);
-                    const double rr = (double)__uint_as_float(r[12]);
-                    kept = rr >= 0.0;
-                    // (zv < D: sub-tiles past the end of a row; x0 < D: the second slab of the last pair when the grid has an odd
-                    // number of x-slabs - such waves walk nothing and their write-out stores nothing, but they pass every barrier)
-                    ok = kept && (zv < D) && (x0 < D) && block_admits(Bz, pz, rc) && (pz + rr >= wz0) && (pz - rr <= wz1) &&
-                         (pxr + rr >= wx0) && (pxr - rr <= wx1);
+                    if constexpr (LR) { // the record's admitted voxel ranges against this wave's sub-tile
+                        const unsigned xr = r[10], yr = r[11], zr = r[12];
+                        kept = xr != EMPTY_RANGE;
+                        ok = kept && (zv < D) && (x0 < D) && ((int)(zr & 0xffff) <= zv + SUBZ - 1) && ((int)(zr >> 16) >= zv) &&
+                             ((int)(xr & 0xffff) <= x0 + SUBX - 1) && ((int)(xr >> 16) >= x0) && ((int)(yr & 0xffff) <= y0 + SUBY - 1) &&
+                             ((int)(yr >> 16) >= y0);
+                    } else {
+                        const double pxr = *reinterpret_cast<const double *>(r);
+                        const double pz = *reinterpret_cast<const double *>(r + 4);
+                        const double rc = *reinterpret_cast<const double *>(r + 10);
+                        const double rr = (double)__uint_as_float(r[12]);
+                        kept = rr >= 0.0;
+                        // (zv < D: sub-tiles past the end of a row; x0 < D: the second slab of the last pair when the grid has an odd
+                        // number of x-slabs - such waves walk nothing and their write-out stores nothing, but they pass every barrier)
+                        ok = kept && (zv < D) && (x0 < D) && block_admits(Bz, pz, rc) && (pz + rr >= wz0) && (pz - rr <= wz1) &&
+                             (pxr + rr >= wx0) && (pxr - rr <= wx1);
+                    }
                 }
                 any = any || __ballot(kept) != 0ull; // (the same rows in every wave: workgroup-uniform)
                 Ops::walk(acc, __ballot(ok), un + (size_t)64 * half * SW, lane, L, P, nullptr, nullptr);
@@ -585,30 +619,36 @@ __global__ void __launch_bounds__(1024) voxelize_pair_kernel(const DirectArgs A,
 // ------------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------------
-template <int CT, bool GAUSS, bool XF>
+template <int CT, bool GAUSS, bool XF, bool LR>
 static hipError_t launch_pair_t(const DirectArgs &d, const VoxParams &p, int64_t max_atoms, float *out, hipStream_t s) {
     static LdsLimit raised;
     VoxParams q = p;
     q.dcap = pair_segw(max_atoms, p.NW);
     const size_t lds = pair_lds_bytes(CT, p.NW, q.dcap);
-    auto kern = &voxelize_pair_kernel<CT, GAUSS, XF>;
+    auto kern = &voxelize_pair_kernel<CT, GAUSS, XF, LR>;
     hipError_t e = raise_lds_limit(kern, lds, raised);
     if (e != hipSuccess) return e;
     launch_profiled(kern, dim3((unsigned)(p.nsy * ((p.nsx + 1) / 2)), (unsigned)(p.B * p.ncc)), dim3(p.NW * 128), lds, s, d, out, q);
     return hipGetLastError();
 }
 
-// float32 grids with whole rows per slab (NW <= 8) and sub-tiles inside one reference block; rows of whole 16-byte quads or
-// not (run-wise write-out), an even number of x-slabs or not (the last pair's second slab then lies outside the grid)
-hipError_t launch_voxelize_pair(const DirectArgs &d, const VoxParams &p, int64_t max_atoms, float *out, int32_t ct, bool gauss, hipStream_t s) {
+// The whole call in one launch: float32 grids with whole rows per slab (NW <= 8); rows of whole 16-byte quads or not (run-wise
+// write-out), an even number of x-slabs or not (the last pair's second slab then lies outside the grid). lane_range: sub-tiles
+// cut by reference blocks (blockdim 4, 5, 12, ...) - built with the transform-capable instantiation only (an identity
+// transform costs that rare case little and keeps the number of kernels down).
+hipError_t launch_voxelize_direct(const DirectArgs &d, const VoxParams &p, int64_t max_atoms, float *out, int32_t ct, bool gauss,
+                                  bool lane_range, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     if (p.NW > 8 || p.nzc != 1 || (long long)p.B * p.ncc > 65535) return hipErrorInvalidConfiguration;
     if (max_atoms > (int64_t)100000000) return hipErrorInvalidConfiguration; // (24-byte rows addressed with 32-bit offsets; plan_call stops at 131 072 atoms)
     const bool xf = d.pa.xforms != nullptr || d.pa.xf_one.flags != 0;
 #define MVX_CASE(CT_)                                                                                                       \
     if (ct == CT_) {                                                                                                        \
-        if (gauss) return xf ? launch_pair_t<CT_, true, true>(d, p, max_atoms, out, s) : launch_pair_t<CT_, true, false>(d, p, max_atoms, out, s);   \
-        return xf ? launch_pair_t<CT_, false, true>(d, p, max_atoms, out, s) : launch_pair_t<CT_, false, false>(d, p, max_atoms, out, s);           \
+        if (lane_range)                                                                                                     \
+            return gauss ? launch_pair_t<CT_, true, true, true>(d, p, max_atoms, out, s) : launch_pair_t<CT_, false, true, true>(d, p, max_atoms, out, s); \
+        if (gauss)                                                                                                          \
+            return xf ? launch_pair_t<CT_, true, true, false>(d, p, max_atoms, out, s) : launch_pair_t<CT_, true, false, false>(d, p, max_atoms, out, s); \
+        return xf ? launch_pair_t<CT_, false, true, false>(d, p, max_atoms, out, s) : launch_pair_t<CT_, false, false, false>(d, p, max_atoms, out, s);   \
     }
     MVX_CASE(1)
     MVX_CASE(4)
@@ -617,6 +657,12 @@ hipError_t launch_voxelize_pair(const DirectArgs &d, const VoxParams &p, int64_t
     MVX_CASE(32)
 #undef MVX_CASE
     return hipErrorInvalidValue;
+}
+
+void scalar_radius_constants(double radius_scalar, float sigma32, bool gauss, double *T, float *k) {
+    const float r32 = (float)radius_scalar;
+    *T = d2_threshold(r32);
+    *k = gauss && *T >= 0.0 ? gauss_coeff(r32, sigma32) : 0.0f;
 }
 
 } // namespace mvx

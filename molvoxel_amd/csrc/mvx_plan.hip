@@ -69,7 +69,7 @@ mvx_plan plan_call(const mvx_plan_query &q, const PlanKnobs &k) {
 
     // ---- route -------------------------------------------------------------------------------------------------------
     plan_slabs(D, 8, false, k.force_nw, p);
-    // One launch for the whole call (voxelize_pair_kernel; voxelize_direct_kernel for per-lane ranges / run-wise grids) when
+    // One launch for the whole call (voxelize_pair_kernel) when
     // the per-workgroup atom scan is cheap next to the slab's stores: per-molecule forward() calls, and a few small
     // molecules per call. Bigger jobs amortise the binning pre-pass.
     // Whole-row slabs only (D <= 64: with rows cut in two the one-launch route loses at every size measured - D = 68 / 72 /

@@ -9,7 +9,6 @@ namespace mvx {
 // round 0.783-0.787, 8: 0.790, 4: 0.792-0.795 - smaller store bursts interleave better between a unit's workgroups.
 constexpr int CR_F32 = 4;
 constexpr int MX_CR = 8;      // matrix-core path: D holds 4 channels x 2 planes per lane and round
-constexpr int DIRECT_CR = 16; // per-molecule launches: 512 workgroups store once, fewer barriers win (cfg-2 call 21.2 -> 20.4 us)
 constexpr int CR64 = 8;       // float64 grids
 
 // ---- pacing of the store stream (profiles/r03_round_pacing.txt) -----------------------------------------------------------
@@ -36,7 +35,6 @@ constexpr long long PACE_EMPTY_MIN_WGS = 4096;
 // waves per SIMD the 1024-thread slab variants (whole rows of 65 ... 128 voxels: 9 ... 16 waves) are compiled for: 8 = 64
 // registers, two or three workgroups per unit (D = 72: 4.16 TB/s against 3.75 with 4 = 128 registers, one workgroup)
 constexpr int BIG_WAVES_PER_SIMD = 8;
-constexpr int DIRECT_WAVES_PER_SIMD = 4; // voxelize_direct_kernel: 128 registers
 
 // ---- host-side plan (plan_call in mvx_plan.hip) ---------------------------------------------------------------------------
 // bytes of pre-pass data (records, keys, feature rows, slab lines: re-read ~20 times) per voxelize launch: what stays in

@@ -82,10 +82,10 @@ def test_no_per_channel_float32_kernels_are_left(res):
     per chunk): the per-channel kernels of rounds 1-3 (200 spilled registers at 32 channels) are gone, and with them every
     float32 instantiation that carried a `chanwise` parameter."""
     assert sum(k.startswith("voxelize_kernel<") for k in res) == 48  # 5 widths x {gaussian, binary} x {plain, lane ranges} x 2 sizes + 8 grouped
-    # per-molecule launches: voxelize_pair_kernel (5 widths x {gaussian, binary} x {no transform, transform}) and, for
-    # per-lane ranges (blockdims that cut through sub-tiles) only, voxelize_direct_kernel (5 widths x {gaussian, binary})
-    assert sum(k.startswith("voxelize_pair_kernel<") for k in res) == 20
-    assert sum(k.startswith("voxelize_direct_kernel<") for k in res) == 10
+    # per-molecule launches: voxelize_pair_kernel alone - 5 widths x {gaussian, binary} x {no transform, transform} plus, for
+    # blockdims that cut through sub-tiles (per-lane ranges), the transform-capable instantiation once more
+    assert sum(k.startswith("voxelize_pair_kernel<") for k in res) == 30
+    assert sum(k.startswith("voxelize_direct_kernel<") for k in res) == 0
 
 
 def test_pair_kernel_fits_one_workgroup_of_sixteen_waves(res):
@@ -96,7 +96,7 @@ def test_pair_kernel_fits_one_workgroup_of_sixteen_waves(res):
     ks = {k: v for k, v in res.items() if k.startswith("voxelize_pair_kernel<")}
     for name, r in ks.items():
         assert r["vgpr"] <= 128, (name, r)
-        no_transform = name.endswith(", false>")
+        no_transform = ", false, false>" in name  # <CT, gauss, transform, lane ranges>
         assert r["scratch"] <= (0 if no_transform else 128), (name, r)  # (452 B once cost the cfg-2 call 30 %: profiles/r04_single_calls.txt)
 
 

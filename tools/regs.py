@@ -7,7 +7,7 @@ import os, re, subprocess, sys, tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "molvoxel_amd/csrc")
-KERNEL_OBJECTS = [os.path.join(CSRC, f"mvx_{name}.o") for name in ("prep", "slab", "direct", "pair", "f64", "splat")
+KERNEL_OBJECTS = [os.path.join(CSRC, f"mvx_{name}.o") for name in ("prep", "slab", "pair", "f64", "splat")
                   if os.path.exists(os.path.join(CSRC, f"mvx_{name}.hip"))]
 
 
