@@ -435,7 +435,8 @@ int run(mvx_handle *h, const RunArgs &r) {
         if (!direct_w && (rc = ensure(w.wbuf, n_alloc * (size_t)Cpad * esz))) return rc;
         if ((rc = ensure(w.xp, n_alloc * sizeof(uint2)))) return rc;
         // x-lists: packed regions, (sum(N) + 2*B) * nsx entries; slab lines: primary + extension entries per slab
-        if ((rc = ensure(w.xlist, ((size_t)total + 2 * (size_t)r.B) * plan.nsx * sizeof(uint2)))) return rc;
+        // (+ 64 B: a wave reads its eight entries of an overflowing slab's list as one group, up to seven past the list's end)
+        if ((rc = ensure(w.xlist, ((size_t)total + 2 * (size_t)r.B) * plan.nsx * sizeof(uint2) + 64))) return rc;
         if ((rc = ensure(w.slist, nslabs * (SLAB_LINE_ENTRIES + SLAB_EXT_ENTRIES) * sizeof(uint2)))) return rc;
     }
     uint2 *d_xlist = reinterpret_cast<uint2 *>(w.xlist.p);

@@ -757,6 +757,7 @@ struct OpsF32 {
     static constexpr int CT = CT_;
     static constexpr bool GROUPED = false;
     static constexpr bool VSTAGE = false;
+    static constexpr bool SPLIT_STAGE = true; // stage_round: a separate copy for groups of eight full slots
     static constexpr bool CULL = true;
     typedef float2v Acc[(CT + 1) / 2];
     static constexpr int WORDS = 1;                   // 32-bit words per channel weight
@@ -835,10 +836,10 @@ __device__ __forceinline__ bool reaches_subtile(const unsigned *r, int lane, con
 template <typename Ops>
 struct RoundSrc {
     const unsigned *src; // this lane's word of row 0 (record word / weight column)
-    size_t stride;       // words between the rows of consecutive atoms, for this lane
+    unsigned stride;     // words between the rows of consecutive atoms, for this lane
     bool stager;         // this lane takes part in staging
     const unsigned *src2; // rows wider than a wave (float64, 32 channels: 16 + 64 words): lanes 0.. fetch words 64.. too
-    size_t stride2;
+    unsigned stride2;
 };
 template <typename Ops>
 constexpr int round_tail() { return 16 + Ops::WW > 64 ? 16 + Ops::WW - 64 : 0; }
@@ -847,44 +848,69 @@ __device__ __forceinline__ RoundSrc<Ops> round_src(const unsigned *__restrict__ 
                                                    const LaneCtx &L, const VoxParams &P) {
     RoundSrc<Ops> R;
     R.src = lane < 16 ? rec + lane : w + (Ops::WORDS * L.cbase + lane - 16);
-    R.stride = lane < 16 ? (size_t)16 : (size_t)(Ops::WORDS * P.w_stride);
+    R.stride = lane < 16 ? 16u : (unsigned)(Ops::WORDS * P.w_stride);
     // (grouped launches read the caller's feature rows in place whatever C is: no column beyond the row)
     R.stager = lane < 16 + Ops::WW && (!Ops::GROUPED || lane < 16 || L.cbase + lane - 16 < P.C);
     R.src2 = w + (Ops::WORDS * L.cbase + lane + 48);
-    R.stride2 = (size_t)(Ops::WORDS * P.w_stride);
+    R.stride2 = (unsigned)(Ops::WORDS * P.w_stride);
     return R;
 }
 
-// Stage a round through registers: eight scalar loads of atom indices, eight row loads in flight, eight LDS writes.
-// BIG: slabs of more than 8 waves (the 1024-thread variants) - slot wave + u * NW then reaches past the 64 rows of a round
-// (and of the LDS region) for the larger u, so those are skipped; with NW <= 8 every slot is below 8 * NW <= 64.
-template <typename Ops, bool BIG>
-__device__ __forceinline__ void stage_round(const uint2 *__restrict__ line, const uint2 *__restrict__ ext, int e0, int n_line,
-                                            unsigned *un, const RoundSrc<Ops> &R, int64_t a0, int lane, int wave, int NW) {
+// Stage a round through registers: the wave's eight slots are CONSECUTIVE entries (slot 8 wave + u), so their atom indices
+// arrive as one 64-byte scalar load group with no per-slot address arithmetic (slots wave + u NW - eight separate s_loads, each
+// with its own 64-bit address, line / extension branch and wait - cost ~39 scalar instructions per slot, 313 per wave and
+// round, on the compute unit's one scalar unit: 740 scalar against 635 vector instructions per wave at a 2.0 A radius,
+// profiles/r04_radius_pmc.txt). A group never straddles line and extension (SLOTS is a multiple of 8). Row order in LDS is the
+// entry order as before: the walk, and every sum, is unchanged. Then eight row loads in flight, eight LDS writes.
+// BIG: slabs of more than 8 waves (the 1024-thread variants) - a round is 64 rows, waves 8.. stage nothing.
+// (ALL: every one of the eight entries is a candidate - the common group; no per-slot test, no exec-mask branches. Row
+// addresses from 32-bit operands - atom indices fit 31 bits, validate() - : one v_mad_u64_u32 per row.)
+template <typename Ops, bool ALL>
+__device__ __forceinline__ void stage_rows(const unsigned (&ai)[8], int g0, int s0, int n_line, unsigned *un, const RoundSrc<Ops> &R,
+                                           unsigned first, int lane) {
     constexpr int SW = Ops::SW;
-    int ai[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { // eight independent scalar loads
-        const int e = e0 + wave + u * NW;
-        ai[u] = (e >= 1 && e <= n_line && (!BIG || wave + u * NW < 64)) ? (int)(e < SLOTS ? line[e].x : ext[e - SLOTS].x) : 0;
-    }
     constexpr int TAIL = round_tail<Ops>();
     unsigned v[8], v2[TAIL ? 8 : 1];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int e = e0 + wave + u * NW;
-        const bool in = e >= 1 && e <= n_line && (!BIG || wave + u * NW < 64);
+        const int e = g0 + u;
+        const bool in = ALL || (e >= 1 && e <= n_line);
         v[u] = 0u;
         if (TAIL) v2[u] = 0u;
-        if (in && R.stager) v[u] = R.src[(size_t)(a0 + ai[u]) * R.stride];
-        if (TAIL && in && lane < TAIL) v2[u] = R.src2[(size_t)(a0 + ai[u]) * R.stride2];
+        if (in && R.stager) v[u] = R.src[(size_t)(first + ai[u]) * R.stride];
+        if (TAIL && in && lane < TAIL) v2[u] = R.src2[(size_t)(first + ai[u]) * R.stride2];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int sl = wave + u * NW, e = e0 + sl;
-        const bool in = e >= 1 && e <= n_line && (!BIG || sl < 64);
+        const int sl = s0 + u, e = g0 + u;
+        const bool in = ALL || (e >= 1 && e <= n_line);
         if (in && (R.stager || (Ops::GROUPED && lane < 16 + Ops::WW))) un[sl * SW + lane] = v[u]; // (v = 0 beyond C)
         if (TAIL && in && lane < TAIL) un[sl * SW + 64 + lane] = v2[u];
+    }
+}
+template <typename Ops, bool BIG>
+__device__ __forceinline__ void stage_round(const uint2 *__restrict__ line, const uint2 *__restrict__ ext, int e0, int n_line,
+                                            unsigned *un, const RoundSrc<Ops> &R, int64_t a0, int lane, int wave, int NW) {
+    static_assert(SLOTS % 8 == 0 && EXT_SLOTS % 8 == 0, "a wave's group of eight entries lies in the line or in its extension");
+    const int s0 = 8 * wave, g0 = e0 + s0; // first slot / entry of this wave (uniform)
+    if ((BIG && wave >= 8) || g0 > n_line) return;
+    const uint2 *__restrict__ grp = g0 < SLOTS ? line + g0 : ext + (g0 - SLOTS);
+    unsigned ai[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ai[u] = grp[u].x; // (entries past n_line: inside the line / the list's slack, unused)
+    if constexpr (Ops::SPLIT_STAGE) {
+        // Branch-free rows. A slot without a candidate (the header's, the ones past the count in the line's last group)
+        // takes the molecule's first row: its row in LDS is inside the 64-row region and nobody walks it. (With per-slot
+        // tests and exec-mask branches in the groups that hold such slots - wave 0's, always - the headline launch ran at
+        // 0.805 of peak instead of 0.833, radius 1.5 A at 0.69 instead of 0.725: same box, profiles/r04_staging.txt.)
+        if (g0 == 0 || g0 + 7 > n_line) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (g0 + u < 1 || g0 + u > n_line) ai[u] = 0u;
+        }
+        stage_rows<Ops, true>(ai, g0, s0, n_line, un, R, (unsigned)a0, lane);
+    } else {
+        stage_rows<Ops, false>(ai, g0, s0, n_line, un, R, (unsigned)a0, lane);
     }
 }
 

@@ -165,6 +165,7 @@ struct OpsMx64 {
     static constexpr bool GROUPED = false;
     static constexpr bool VSTAGE = false;
     static constexpr bool CULL = true;
+    static constexpr bool SPLIT_STAGE = true;
     struct Acc {
         d4v a[2][4]; // [channel block of 16][voxel block m = 2 x + yh]: channels 16 cb + 4 r + lane / 16, r = 0..3
     };
@@ -310,6 +311,7 @@ struct OpsMx64 {
 template <int CT_, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
 struct OpsF64 {
     static constexpr bool RUNS = false;
+    static constexpr bool SPLIT_STAGE = true;
     static constexpr int CT = CT_;
     typedef double Acc[CT];
     static constexpr int WORDS = 2;
