@@ -532,6 +532,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.b0 = 0;
     va.p.c0 = 0;
     va.p.NW = plan.nw;
+    va.p.nslab = (uint32_t)(plan.nsx * plan.nsy * plan.nzc);
     va.p.w_stride = plan.grouped ? r.C : Cpad;
     va.p.dcap = f64 ? (mx64 ? 0 : 64) : 0; // (float64: rows per round of the general slab loop, 0 selects the matrix-core kernel)
     va.p.vec_store = plan.vec_store;

@@ -84,6 +84,8 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
     int32_t b0;            // first molecule of this launch (blockIdx.y = (molecule - b0) * ncc + channel chunk)
     int32_t c0;            // first channel of this launch's chunks (voxelize_kernel: a remainder launch with a narrower kernel)
     int32_t NW;            // waves per workgroup = 4^3 sub-tiles per slab
+    uint32_t nslab;        // nsx * nsy * nzc: slabs per molecule (the kernels' line index; not gridDim.x - an implicit argument, one more
+                           // scalar round trip in front of the line's header)
     int32_t w_stride;      // floats between the channel weights of consecutive atoms
     int32_t dcap;          // candidate rows staged per round
     int32_t vec_store;     // D % 4 == 0 and out 16-B aligned

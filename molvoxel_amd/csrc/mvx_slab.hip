@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(512, narrow_waves_per_simd(CT, NSUB))
         cc = (int)blockIdx.y - b * P.ncc;
     }
     b += P.b0;
-    const uint2 *__restrict__ line = slist + ((size_t)b * (size_t)gridDim.x + t) * SLOTS; // (uniform: scalar loads)
+    const uint2 *__restrict__ line = slist + ((size_t)b * (size_t)P.nslab + t) * SLOTS; // (uniform: scalar loads)
     const uint2 hdr = line[0];
     int sx, sy, zc;
     decode_slab(t, P, sx, sy, zc);
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(512, narrow_waves_per_simd(CT, NSUB))
     const unsigned first = __builtin_amdgcn_readfirstlane(hdr.y); // the molecule's first atom (atom indices fit 31 bits)
     if (n_hdr > 0) {
         const bool xl = __builtin_expect(n_hdr > (unsigned)LINE_CAP, 0); // the slab walks its (molecule, x-slab) list (mvx_slab_body.inc)
-        const uint2 *__restrict__ ext = slist_ext + ((size_t)b * (size_t)gridDim.x + t) * EXT_SLOTS;
+        const uint2 *__restrict__ ext = slist_ext + ((size_t)b * (size_t)P.nslab + t) * EXT_SLOTS;
         int n = (int)n_hdr;
         if (xl) {
             const uint2 where = line[1];
