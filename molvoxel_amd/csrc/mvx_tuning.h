@@ -20,8 +20,10 @@ constexpr int EMPTY_SPLIT = 20;
 // A light slab of a store-bound launch waits after each write-out round about as long as a compute unit needs to drain the
 // round's bytes: 8 channels x 64 NW voxels x 4 B at ~12.8 B per cycle = 2.5 NW units (NW = 8: 20 units = 1280 cycles; cfg-2 x
 // 256 of peak, 4 / 16 / 20 / 24 / 30 / 40 units: +0.5 / +2.3 / +2.5...4.7 / +2 / +0.5 / -7 %). Issued as NW/2 sleeps of
-// ROUND_SLEEP_STEP units (s_sleep takes an immediate).
-constexpr int ROUND_SLEEP_STEP = 5;
+// ROUND_SLEEP_STEP units (s_sleep takes an immediate). Re-measured after the staging lost its scalar work (the slabs reach
+// their write-out sooner; profiles/r04_staging.txt), same box, of peak: 4 / 5 / 6 / 7 / 8 / 10 units per step 0.798 / 0.811-0.829 /
+// 0.818-0.833 / 0.826 / 0.809 / 0.76: 6 is +0.4 ... 0.8 % over 5 in each of three runs.
+constexpr int ROUND_SLEEP_STEP = 6;
 // ... only slabs of at most this many candidates: heavier slabs are bound by their walk and lose by waiting (1.5 A radius:
 // -5 % with every slab paced, +1 % with the limit; 2.0 A: +2 %)
 constexpr int PACE_MAX_CANDIDATES = 48;
