@@ -757,7 +757,8 @@ struct OpsF32 {
     static constexpr int CT = CT_;
     static constexpr bool GROUPED = false;
     static constexpr bool VSTAGE = false;
-    static constexpr bool SPLIT_STAGE = true; // stage_round: a separate copy for groups of eight full slots
+    static constexpr bool SPLIT_STAGE = true; // stage_round: no per-slot tests
+    static constexpr bool PRESTAGE = false;
     static constexpr bool CULL = true;
     typedef float2v Acc[(CT + 1) / 2];
     static constexpr int WORDS = 1;                   // 32-bit words per channel weight
@@ -911,6 +912,64 @@ __device__ __forceinline__ void stage_round(const uint2 *__restrict__ line, cons
         stage_rows<Ops, true>(ai, g0, s0, n_line, un, R, (unsigned)a0, lane);
     } else {
         stage_rows<Ops, false>(ai, g0, s0, n_line, un, R, (unsigned)a0, lane);
+    }
+}
+
+// The first TWO rounds of a slab staged at once (Ops::PRESTAGE: the 32-channel matrix-core kernels, whose row region holds
+// 2 RW rows): a dense slab's second round costs a second trip through the vector memory pipeline - ~5 kcycles behind the
+// compute unit's stores - plus two barriers when it is staged after the first walk (phase timelines, profiles/r04_staging.txt:
+// radius 2.0 A, two to three rounds per slab: 35 kcycles per workgroup, 16-18 of them "walk"). Before the first walk the 32
+// accumulator registers are not alive yet: both rounds' rows travel together (16 registers), one barrier, and the second
+// round is walked straight from its own rows at un + RW * SW. Returns nothing; the caller walks round 1 when n_line >= RW.
+template <typename Ops, bool BIG>
+__device__ __forceinline__ void stage_first_rounds(const uint2 *__restrict__ line, const uint2 *__restrict__ ext, int n_line, int RW,
+                                                   unsigned *un, const RoundSrc<Ops> &R, int64_t a0, int lane, int wave) {
+    static_assert(round_tail<Ops>() == 0, "rows of at most 64 words");
+    constexpr int SW = Ops::SW;
+    const int s0 = 8 * wave; // first slot of this wave in either round (uniform)
+    if ((BIG && wave >= 8) || s0 > n_line) return;
+    const int g1 = RW + s0;
+    const bool two = g1 <= n_line; // (uniform) this wave holds rows of the second round as well
+    const unsigned first = (unsigned)a0;
+    unsigned ai0[8], ai1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ai0[u] = line[s0 + u].x; // (s0 < 64 = SLOTS)
+    if (two) {
+        const uint2 *__restrict__ grp = g1 < SLOTS ? line + g1 : ext + (g1 - SLOTS);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ai1[u] = grp[u].x;
+        if (g1 + 7 > n_line) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (g1 + u > n_line) ai1[u] = 0u;
+        }
+    }
+    if (s0 == 0 || s0 + 7 > n_line) { // the header's slot, slots past the count: the molecule's first row, never walked
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s0 + u < 1 || s0 + u > n_line) ai0[u] = 0u;
+    }
+    unsigned v0[8], v1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        v0[u] = 0u;
+        if (R.stager) v0[u] = R.src[(size_t)(first + ai0[u]) * R.stride];
+    }
+    if (two) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v1[u] = 0u;
+            if (R.stager) v1[u] = R.src[(size_t)(first + ai1[u]) * R.stride];
+        }
+    }
+    const bool writer = R.stager || (Ops::GROUPED && lane < 16 + Ops::WW); // (v = 0 beyond C)
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (writer) un[(s0 + u) * SW + lane] = v0[u];
+    if (two) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (writer) un[(g1 + u) * SW + lane] = v1[u];
     }
 }
 

@@ -37,6 +37,7 @@ struct OpsMx32 {
     static constexpr bool GROUPED = GROUPED_;
     static constexpr bool VSTAGE = false;
     static constexpr bool SPLIT_STAGE = true;
+    static constexpr bool PRESTAGE = true; // the row region holds two rounds: stage_first_rounds
     static constexpr bool CULL = true;
     struct Acc {
         f16v p0, p1; // the x0 plane and the x0 + 1 plane of the sub-tile
@@ -235,6 +236,7 @@ struct OpsPair {
     static constexpr bool GROUPED = false;
     static constexpr bool VSTAGE = true;
     static constexpr bool SPLIT_STAGE = false;
+    static constexpr bool PRESTAGE = false;
     // no per-wave sphere / box cull of the staged rows (reaches_subtile): ~35 vector instructions per wave and round to drop
     // 1-2 of a wave's ~8 candidates at 17 (Gaussian) or 12 (binary) instructions each - same box, culled -> not culled,
     // kernel: forward_single 0.121 -> 0.118 ms, 8 types 0.173 -> 0.167, cfg-3 x 256 0.238 -> 0.217 (profiles/r04_narrow.txt)

@@ -30,7 +30,8 @@ size_t voxelize_lds_bytes(int32_t ct, int32_t NW, int32_t crmax) {
     return tile > cand ? tile : cand;
 }
 
-static size_t voxelize_mx_lds_bytes(int32_t NW) { return voxelize_lds_bytes(32, NW, MX_CR); }
+// (the matrix-core kernels keep the rows of TWO rounds: stage_first_rounds)
+static size_t voxelize_mx_lds_bytes(int32_t NW) { return std::max(voxelize_lds_bytes(32, NW, MX_CR), (size_t)2 * 64 * cand_stride_words(32) * 4); }
 
 // voxelize_kernel's arithmetic: 32-channel chunks go to the matrix cores (OpsMx32), narrower chunks to the vector ALU in
 // candidate pairs (OpsPair); the per-lane-range variants keep one voxel per lane and candidate (OpsF32)

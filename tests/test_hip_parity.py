@@ -349,6 +349,37 @@ def test_medium_density_multi_round_slab_lines(mv):
     assert_gaussian(outg, refg)  # sums of up to ~60 terms
 
 
+@pytest.mark.parametrize("variant", ["plain", "lane_range", "channel_wise", "runs", "six_waves", "nine_waves"])
+def test_candidate_counts_around_the_rounds_staged_together(mv, variant):
+    """The 32-channel kernels stage the first TWO rounds of a slab's line at once (stage_first_rounds: rows 0 .. 2 RW - 1 of
+    the row region) and walk the second round without a barrier; a third round goes through the row region again. A cluster
+    of exactly k atoms inside one sub-tile makes k the candidate count of that slab: every count around RW and 2 RW (RW = 64
+    rows, 48 on the six-wave slabs of a 48^3 grid), in every kernel family that shares the staging - plain, per-lane ranges
+    (blockdim 5), grouped channel-wise radii, the run-wise write-out (D = 50), slabs of six and of nine waves. Binned route
+    against the oracle and, bit for bit, against the one-launch route."""
+    from oracle import c_oracle
+
+    D = {"runs": 50, "six_waves": 48, "nine_waves": 72}.get(variant, 64)
+    RW = 48 if variant == "six_waves" else 64
+    kw = {"blockdim": 5} if variant == "lane_range" else {}
+    rt = "channel-wise" if variant == "channel_wise" else "scalar"
+    rng = np.random.default_rng(sum(map(ord, variant)))
+    vox = mv.create_voxelizer(0.5, D, rt, "gaussian", "hip", output="numpy", sigma=0.8, **kw)
+    for k in (RW - 2, RW - 1, RW, RW + 1, RW + 9, 2 * RW - 1, 2 * RW, 2 * RW + 1, 2 * RW + 17, 3 * RW + 5):
+        c0 = rng.uniform(-3.0, 3.0, 3)
+        xyz = np.concatenate([c0 + rng.uniform(-0.2, 0.2, (k, 3)), rng.uniform(-0.25 * D, 0.25 * D, (40, 3))])
+        f = rng.random((len(xyz), 32)).astype(np.float32)
+        radii = np.linspace(0.8, 1.4, 32)[rng.permutation(32)] if rt == "channel-wise" else 1.0
+        radii = np.round(radii * 4) / 4 if rt == "channel-wise" else radii  # a few distinct radii: grouped slots
+        ref = c_oracle.voxelize(xyz, f, radii, dimension=D, density="gaussian", sigma=0.8, radii_type=rt, blockdim=kw.get("blockdim"))
+        vox.debug_option("direct", 0)
+        out = vox.forward(xyz, None, f, radii).copy()
+        assert_gaussian(out, ref)
+        if rt != "channel-wise":  # (channel-wise features never take the one-launch route)
+            vox.debug_option("direct", 1)
+            assert np.array_equal(vox.forward(xyz, None, f, radii), out), f"routes disagree at {k} candidates"
+
+
 @pytest.mark.parametrize("D,C_,blockdim", [(70, 16, None), (120, 16, None), (70, 32, 5), (120, 32, 5), (72, 32, None), (100, 8, None)])
 def test_whole_row_slabs_of_long_rows_with_more_than_64_candidates(mv, D, C_, blockdim):
     """Rows of 65 ... 128 voxels stay in one slab of 9 ... 16 waves (plan_slabs). A round still holds 64 rows: the staging
