@@ -39,7 +39,7 @@ def test_batched_voxelize_kernels_fit_their_occupancy(res):
     # the cold rounds, never the accumulators
     for name, r in ks.items():
         if name.startswith("voxelize_kernel<32,"):
-            assert r["vspill"] <= 16 and r["scratch"] <= 80, (name, r)
+            assert r["vspill"] <= 20 and r["scratch"] <= 80, (name, r)  # (17: grouped + per-lane ranges, the rarest variant)
 
 
 def test_whole_row_slabs_of_long_rows_keep_two_workgroups_per_unit(res):
@@ -66,8 +66,9 @@ def test_float64_matrix_core_kernel_keeps_two_workgroups_per_unit(res):
     for name, r in res.items():
         if name.startswith("voxelize64_kernel<"):
             assert r["vgpr"] <= 128, (name, r)
-            assert r["scratch"] <= 160, (name, r)
-    assert res["voxelize64_kernel<false, false, 512>"]["scratch"] == 0
+            assert r["scratch"] <= 32, (name, r)  # (the Gaussian per-lane-range variant: 3 registers; the others none)
+    for name in ("voxelize64_kernel<false, false, 512>", "voxelize64_kernel<false, true, 512>", "voxelize64_kernel<true, false, 512>"):
+        assert res[name]["scratch"] == 0, (name, res[name])
 
 
 def test_prepass_kernels_do_not_spill_vector_registers(res):
