@@ -133,7 +133,7 @@ def pcie_inclusive(steps=5):
 
 
 def pacing_rows(steps=40, warmup=60):
-    """Guard rows for the pacing thresholds (mvx_tuning.h: write-out rounds paced from 32 768 workgroups = 64 cfg-2
+    """Guard rows for the pacing thresholds (mvx_tuning.h: write-out rounds paced from 49 152 workgroups = 96 cfg-2
     molecules, empty slabs held back beyond 4 096): cfg-2 at 16 / 64 / 96 / 256 molecules per call and cfg-4 x 128, kernel
     TB/s of algorithmic bytes. Re-run whenever the slab kernels change: a threshold that has drifted shows up as a dip at
     64 -> 96 or as cfg-4 falling below ~0.8 of peak (round 3: 0.715 / 0.785 / 0.80 / 0.80 of peak, cfg-4 0.85)."""

@@ -89,7 +89,7 @@ struct VoxParams { // by-value kernel parameters (scalars only: pointers are sep
     int32_t w_stride;      // floats between the channel weights of consecutive atoms
     int32_t dcap;          // candidate rows staged per round
     int32_t vec_store;     // D % 4 == 0 and out 16-B aligned
-    int32_t pace;          // 1: empty slabs hold their stores back ~1.7 us (launches of more than 4096 workgroups); 2: light slabs pace their write-out rounds too (>= 32 768)
+    int32_t pace;          // 1: empty slabs hold their stores back ~1.7 us (launches of more than 4096 workgroups); 2: light slabs pace their write-out rounds too (>= 49 152)
     int32_t xcd_ranges;    // 1: every XCD takes a contiguous range of slabs (run-wise write-out of whole-row slabs; gridDim.x = 8 ceil(T / 8))
     double sigma;          // float64 grids: the Gaussian sigma as the reference holds it (python float)
 #ifdef MVX_DIAG

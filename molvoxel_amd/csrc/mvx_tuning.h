@@ -30,9 +30,9 @@ constexpr int PACE_MAX_CANDIDATES = 48;
 // ... and only in launches of at least PACE_ROUNDS_MIN_WGS workgroups (96 cfg-2 molecules; unpaced -> paced, of peak: 16
 // molecules 0.734 -> 0.715, 32: 0.767 -> 0.745, 64: 0.773 -> 0.785, 128: 0.775 -> 0.801, 256: 0.768 -> 0.801); empty slabs
 // are held back in launches of more than PACE_EMPTY_MIN_WGS workgroups (a small launch would just start later)
-// (after the staging change, same box, kernel of peak unpaced / paced: 16 molecules 0.757 / 0.735, 32: 0.77 / 0.77, 64: 0.791 / 0.807:
-// the limit moved from 49 152 to 32 768 workgroups)
-constexpr long long PACE_ROUNDS_MIN_WGS = 32768;
+// (after the staging change, same box, kernel of peak unpaced / paced: 16 molecules 0.757 / 0.735, 32: 0.77 / 0.77, 64 in a
+// sustained loop 0.791 / 0.807 - but 64 in bursts of 20 calls, tools/variants.py: 0.394 / 0.417 ms per call: the limit stays)
+constexpr long long PACE_ROUNDS_MIN_WGS = 49152;
 constexpr long long PACE_EMPTY_MIN_WGS = 4096;
 
 // ---- occupancy targets ------------------------------------------------------------------------------------------------------

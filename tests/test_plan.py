@@ -117,12 +117,11 @@ def test_infinity_cache_chunks_and_grid_limits():
 
 
 def test_pacing_thresholds():
-    """mvx_tuning.h: rounds paced from 32 768 workgroups (64 cfg-2 molecules gain 2 %, 32 tie, 16 lose 3 %), empty slabs held
-    back beyond 4 096."""
+    """mvx_tuning.h: rounds paced from 49 152 workgroups (96 cfg-2 molecules: 64 molecules gain 2 % in a sustained loop and lose
+    5 % in short bursts, 128 gain 3 %), empty slabs held back beyond 4 096."""
     assert plan(64, 32, 8, 4000)["pace"] == 0
     assert plan(64, 32, 16, 4000)["pace"] == 1
-    assert plan(64, 32, 63, 4000)["pace"] == 1
-    assert plan(64, 32, 64, 4000)["pace"] == 2
+    assert plan(64, 32, 64, 4000)["pace"] == 1
     assert plan(64, 32, 96, 4000)["pace"] == 2
     assert plan(64, 32, 256, 4000)["pace"] == 2
 

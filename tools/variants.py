@@ -2,13 +2,19 @@
 call): looks for performance cliffs.   python3 tools/variants.py"""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("LIB"):  # another build of the library (A/B): path relative to the repo root
+    from molvoxel_amd.voxelizer.hip import _lib as _l
+    _l.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ["LIB"])
 import molvoxel_amd
+ONLY = os.environ.get("ONLY")  # substring filter over the row names
 
 B, N = 64, 4000
 rng = np.random.default_rng(0)
 
 
-def run(name, D, radii_type, density, mode, C, radii, res=0.5, transform=False, **kw):
+def run(name, D, radii_type, density, mode, C, radii, res=0.5, transform=False, N=N, **kw):
+    if ONLY and ONLY not in name:
+        return
     W = res * (D - 1)
     vox = molvoxel_amd.create_voxelizer(res, D, radii_type, density, library="hip", **kw)
     xyz = rng.uniform(-W / 2, W / 2, (B * N, 3))
@@ -57,6 +63,7 @@ run("features C=64", 64, "scalar", "gaussian", "features", 64, 1.0)
 run("features C=33", 64, "scalar", "gaussian", "features", 33, 1.0)
 run("D=50 (not a multiple of 4: run-wise write-out)", 50, "scalar", "gaussian", "features", 32, 1.0)
 run("D=48", 48, "scalar", "gaussian", "features", 32, 1.0)
+run("D=48 at cfg-2 density (1 688 atoms per molecule)", 48, "scalar", "gaussian", "features", 32, 1.0, N=1688)
 run("D=96", 96, "scalar", "gaussian", "features", 16, 1.0)
 run("blockdim=5 (sub-tiles straddle reference blocks)", 64, "scalar", "gaussian", "features", 32, 1.0, blockdim=5)
 run("blockdim=64 (no block cull)", 64, "scalar", "gaussian", "features", 32, 1.0, blockdim=64)
