@@ -40,6 +40,12 @@ void plan_slabs(int D, int max_waves, bool whole_rows, int force_nw, mvx_plan &p
         const int k = (nsz + 15) / 16;
         p.nw = (nsz + k - 1) / k;
     }
+    // rows of 8 k + 4 sub-tiles cut into chunks of 8 (D = 96, 160, 224: multiples of 128 B) leave a last chunk whose slabs
+    // run half empty - four of eight waves idle through every barrier. The store-bound 32-channel launches do not notice (D = 96,
+    // kernel TB/s of grid bytes, chunks of 8 / 4: C = 32 5.72 / 5.66, C = 64 5.60 / 5.33); narrow chunks, which are bound by their
+    // walk, gain what the idle waves cost: C = 16 4.39 -> 5.91 (4 000 atoms) and 3.73 -> 4.67 (13 500), C = 8 3.83 -> 4.63 and
+    // 3.11 -> 3.62, C = 4 3.03 -> 3.32 (tools/d_kernel_probe.py, 19 molecules per call)
+    if (whole_rows && p.ct < 32 && nsz > 8 && nsz % 8 == 4 && p.nw == 8) p.nw = 4;
     if (force_nw > 0 && force_nw <= 16) p.nw = std::min(force_nw, nsz); // "nw" measurement knob
     p.nzc = (nsz + p.nw - 1) / p.nw;
 }

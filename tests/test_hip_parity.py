@@ -349,6 +349,32 @@ def test_medium_density_multi_round_slab_lines(mv):
     assert_gaussian(outg, refg)  # sums of up to ~60 terms
 
 
+@pytest.mark.parametrize("C_,mode", [(1, "single"), (4, "types"), (8, "features"), (16, "features"), (40, "features")])
+def test_rows_of_twelve_sub_tiles_in_chunks_of_four(mv, C_, mode):
+    """D = 96: narrow launches cut the row into three chunks of four sub-tiles (plan_slabs), 32-channel chunks into 8 + 4;
+    C = 40 keeps the 8 + 4 plan for its 32-channel launch and its 8-channel remainder launch alike. Against the oracle."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(960 + C_)
+    D, n = 96, 5000
+    W_ = 0.5 * (D - 1)
+    xyz = rng.uniform(-W_ / 2, W_ / 2, (n, 3))
+    for density in ("gaussian", "binary"):
+        v = mv.create_voxelizer(0.5, D, "scalar", density, "hip", output="numpy", sigma=0.6)
+        if mode == "single":
+            out = v.forward_single(xyz, None, 1.25)
+            ref = c_oracle.voxelize(xyz, None, 1.25, dimension=D, density=density, sigma=0.6)
+        elif mode == "types":
+            t = rng.integers(0, C_, n)
+            out = v.forward_types(xyz, None, t, 1.25)
+            ref = c_oracle.voxelize(xyz, t, 1.25, dimension=D, density=density, sigma=0.6, num_channels=C_)
+        else:
+            f = rng.random((n, C_)).astype(np.float32)
+            out = v.forward_features(xyz, None, f, 1.25)
+            ref = c_oracle.voxelize(xyz, f, 1.25, dimension=D, density=density, sigma=0.6)
+        _compare(out, ref, density == "binary" and mode != "features")  # (binary features: sums of float32 products, the Gaussian rule)
+
+
 @pytest.mark.parametrize("variant", ["plain", "lane_range", "channel_wise", "runs", "six_waves", "nine_waves"])
 def test_candidate_counts_around_the_rounds_staged_together(mv, variant):
     """The 32-channel kernels stage the first TWO rounds of a slab's line at once (stage_first_rounds: rows 0 .. 2 RW - 1 of

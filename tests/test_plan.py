@@ -116,6 +116,17 @@ def test_infinity_cache_chunks_and_grid_limits():
     assert plan(16, 64, 40000, 4)["nchunk"] >= 2
 
 
+def test_rows_of_8k_plus_4_sub_tiles_take_chunks_of_four_in_narrow_launches():
+    """D = 96 / 160 / 224: chunks of 8 sub-tiles leave a last chunk whose slabs are half empty. Launches that are bound by their
+    walk (fewer than 32 channels per workgroup) take chunks of 4 (C = 16: 4.39 -> 5.91 TB/s); 32-channel chunks keep 8."""
+    for C_, nw, nzc in ((4, 4, 3), (8, 4, 3), (16, 4, 3), (32, 8, 2), (64, 8, 2), (33, 8, 2)):
+        p = plan(96, C_, 19, 4000)
+        assert (p["nw"], p["nzc"]) == (nw, nzc), (C_, p)
+    assert (plan(160, 16, 4, 4000)["nw"], plan(160, 16, 4, 4000)["nzc"]) == (4, 5)
+    assert (plan(128, 16, 8, 4000)["nw"], plan(128, 16, 8, 4000)["nzc"]) == (8, 2)  # (whole chunks: nothing idle)
+    assert plan(100, 16, 8, 4000)["nw"] == 13  # (rows that are not multiples of 32 voxels stay whole)
+
+
 def test_pacing_thresholds():
     """mvx_tuning.h: rounds paced from 49 152 workgroups (96 cfg-2 molecules: 64 molecules gain 2 % in a sustained loop and lose
     5 % in short bursts, 128 gain 3 %), empty slabs held back beyond 4 096."""
