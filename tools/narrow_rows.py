@@ -22,6 +22,7 @@ ROWS = {  # name: (mode, C, density, D, N, B)
     "feat16": ("features", 16, "gaussian", 64, 4000, 64),
     "cfg3x256": ("types", 4, "binary", 48, 1000, 256),
     "cfg1x256": ("features", 5, "gaussian", 64, 4000, 256),
+    "lig8x128": ("types", 8, "gaussian", 64, 50, 128),  # ligand-sized molecules: mostly empty slabs
 }
 CALLS = int(os.environ.get("CALLS", 30))
 
