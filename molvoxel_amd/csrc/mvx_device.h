@@ -757,7 +757,6 @@ struct OpsF32 {
     static constexpr int CT = CT_;
     static constexpr bool GROUPED = false;
     static constexpr bool VSTAGE = false;
-    static constexpr bool SPLIT_STAGE = true; // stage_round: no per-slot tests
     static constexpr bool PRESTAGE = false;
     static constexpr bool CULL = true;
     typedef float2v Acc[(CT + 1) / 2];
@@ -861,32 +860,31 @@ __device__ __forceinline__ RoundSrc<Ops> round_src(const unsigned *__restrict__ 
 // arrive as one 64-byte scalar load group with no per-slot address arithmetic (slots wave + u NW - eight separate s_loads, each
 // with its own 64-bit address, line / extension branch and wait - cost ~39 scalar instructions per slot, 313 per wave and
 // round, on the compute unit's one scalar unit: 740 scalar against 635 vector instructions per wave at a 2.0 A radius,
-// profiles/r04_radius_pmc.txt). A group never straddles line and extension (SLOTS is a multiple of 8). Row order in LDS is the
-// entry order as before: the walk, and every sum, is unchanged. Then eight row loads in flight, eight LDS writes.
+// profiles/r04_staging.txt). A group never straddles line and extension (SLOTS is a multiple of 8). Row order in LDS is the
+// entry order as before: the walk, and every sum, is unchanged. Then eight row loads in flight, eight LDS writes - without
+// per-slot tests or exec-mask branches: a slot without a candidate (the header's, the ones past the count in the line's last
+// group) takes the molecule's first row; its row in LDS is inside the 64-row region and nobody walks it. (With tests and
+// branches in the groups that hold such slots - wave 0's, always - the headline launch ran at 0.805 of peak instead of 0.833,
+// radius 1.5 A at 0.69 instead of 0.725, same box.) Row addresses from 32-bit operands (atom indices fit 31 bits, validate()):
+// one v_mad_u64_u32 per row.
 // BIG: slabs of more than 8 waves (the 1024-thread variants) - a round is 64 rows, waves 8.. stage nothing.
-// (ALL: every one of the eight entries is a candidate - the common group; no per-slot test, no exec-mask branches. Row
-// addresses from 32-bit operands - atom indices fit 31 bits, validate() - : one v_mad_u64_u32 per row.)
-template <typename Ops, bool ALL>
-__device__ __forceinline__ void stage_rows(const unsigned (&ai)[8], int g0, int s0, int n_line, unsigned *un, const RoundSrc<Ops> &R,
-                                           unsigned first, int lane) {
+template <typename Ops>
+__device__ __forceinline__ void stage_rows(const unsigned (&ai)[8], int s0, unsigned *un, const RoundSrc<Ops> &R, unsigned first, int lane) {
     constexpr int SW = Ops::SW;
     constexpr int TAIL = round_tail<Ops>();
     unsigned v[8], v2[TAIL ? 8 : 1];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int e = g0 + u;
-        const bool in = ALL || (e >= 1 && e <= n_line);
         v[u] = 0u;
         if (TAIL) v2[u] = 0u;
-        if (in && R.stager) v[u] = R.src[(size_t)(first + ai[u]) * R.stride];
-        if (TAIL && in && lane < TAIL) v2[u] = R.src2[(size_t)(first + ai[u]) * R.stride2];
+        if (R.stager) v[u] = R.src[(size_t)(first + ai[u]) * R.stride];
+        if (TAIL && lane < TAIL) v2[u] = R.src2[(size_t)(first + ai[u]) * R.stride2];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int sl = s0 + u, e = g0 + u;
-        const bool in = ALL || (e >= 1 && e <= n_line);
-        if (in && (R.stager || (Ops::GROUPED && lane < 16 + Ops::WW))) un[sl * SW + lane] = v[u]; // (v = 0 beyond C)
-        if (TAIL && in && lane < TAIL) un[sl * SW + 64 + lane] = v2[u];
+        const int sl = s0 + u;
+        if (R.stager || (Ops::GROUPED && lane < 16 + Ops::WW)) un[sl * SW + lane] = v[u]; // (v = 0 beyond C)
+        if (TAIL && lane < TAIL) un[sl * SW + 64 + lane] = v2[u];
     }
 }
 template <typename Ops, bool BIG>
@@ -898,21 +896,13 @@ __device__ __forceinline__ void stage_round(const uint2 *__restrict__ line, cons
     const uint2 *__restrict__ grp = g0 < SLOTS ? line + g0 : ext + (g0 - SLOTS);
     unsigned ai[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) ai[u] = grp[u].x; // (entries past n_line: inside the line / the list's slack, unused)
-    if constexpr (Ops::SPLIT_STAGE) {
-        // Branch-free rows. A slot without a candidate (the header's, the ones past the count in the line's last group)
-        // takes the molecule's first row: its row in LDS is inside the 64-row region and nobody walks it. (With per-slot
-        // tests and exec-mask branches in the groups that hold such slots - wave 0's, always - the headline launch ran at
-        // 0.805 of peak instead of 0.833, radius 1.5 A at 0.69 instead of 0.725: same box, profiles/r04_staging.txt.)
-        if (g0 == 0 || g0 + 7 > n_line) {
+    for (int u = 0; u < 8; ++u) ai[u] = grp[u].x; // (entries past n_line: inside the line / the list's slack, replaced below)
+    if (g0 == 0 || g0 + 7 > n_line) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (g0 + u < 1 || g0 + u > n_line) ai[u] = 0u;
-        }
-        stage_rows<Ops, true>(ai, g0, s0, n_line, un, R, (unsigned)a0, lane);
-    } else {
-        stage_rows<Ops, false>(ai, g0, s0, n_line, un, R, (unsigned)a0, lane);
+        for (int u = 0; u < 8; ++u)
+            if (g0 + u < 1 || g0 + u > n_line) ai[u] = 0u;
     }
+    stage_rows<Ops>(ai, s0, un, R, (unsigned)a0, lane);
 }
 
 // The first TWO rounds of a slab staged at once (Ops::PRESTAGE: the 32-channel matrix-core kernels, whose row region holds

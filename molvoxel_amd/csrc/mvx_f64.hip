@@ -165,7 +165,6 @@ struct OpsMx64 {
     static constexpr bool GROUPED = false;
     static constexpr bool VSTAGE = false;
     static constexpr bool CULL = true;
-    static constexpr bool SPLIT_STAGE = true;
     static constexpr bool PRESTAGE = false;
     struct Acc {
         d4v a[2][4]; // [channel block of 16][voxel block m = 2 x + yh]: channels 16 cb + 4 r + lane / 16, r = 0..3
@@ -312,7 +311,6 @@ struct OpsMx64 {
 template <int CT_, bool GAUSS, bool CHANWISE, bool LANE_RANGE>
 struct OpsF64 {
     static constexpr bool RUNS = false;
-    static constexpr bool SPLIT_STAGE = true;
     static constexpr bool PRESTAGE = false;
     static constexpr int CT = CT_;
     typedef double Acc[CT];

@@ -36,7 +36,6 @@ struct OpsMx32 {
     static constexpr bool RUNS = RUNS_; // carries the run-wise write-out (store_runs)
     static constexpr bool GROUPED = GROUPED_;
     static constexpr bool VSTAGE = false;
-    static constexpr bool SPLIT_STAGE = true;
     static constexpr bool PRESTAGE = true; // the row region holds two rounds: stage_first_rounds
     static constexpr bool CULL = true;
     struct Acc {
@@ -235,7 +234,6 @@ struct OpsPair {
     static constexpr bool RUNS = RUNS_; // carries the run-wise write-out (store_runs): the per-molecule kernel only
     static constexpr bool GROUPED = false;
     static constexpr bool VSTAGE = true;
-    static constexpr bool SPLIT_STAGE = false;
     static constexpr bool PRESTAGE = false;
     // no per-wave sphere / box cull of the staged rows (reaches_subtile): ~35 vector instructions per wave and round to drop
     // 1-2 of a wave's ~8 candidates at 17 (Gaussian) or 12 (binary) instructions each - same box, culled -> not culled,
