@@ -27,7 +27,7 @@ int pick_ct(int C) {
 // TB/s of grid bytes, chunks -> whole rows: D = 72 1.80 -> 4.16, 88 1.94 -> 4.02, 104 2.12 -> 4.03, 120 2.25 -> 3.81,
 // 80 3.70 -> 4.12, 112 3.95 -> 4.02, 65 2.13 -> 2.57; D = 96 4.26 -> 4.28 and D = 128 5.13 -> 4.22 keep their chunks
 // (tools/odd_d_probe.py ROW_SWEEP=1, profiles/r03_odd_dimensions.txt).
-void plan_slabs(int D, int max_waves, bool whole_rows, int force_nw, mvx_plan &p) {
+void plan_slabs(int D, int max_waves, bool whole_rows, int force_nw, mvx_plan &p, bool quad_rows = false) {
     p.nsx = (D + SUBX - 1) / SUBX;
     p.nsy = (D + SUBY - 1) / SUBY;
     const int nsz = (D + SUBZ - 1) / SUBZ;
@@ -46,6 +46,15 @@ void plan_slabs(int D, int max_waves, bool whole_rows, int force_nw, mvx_plan &p
     // walk, gain what the idle waves cost: C = 16 4.39 -> 5.91 (4 000 atoms) and 3.73 -> 4.67 (13 500), C = 8 3.83 -> 4.63 and
     // 3.11 -> 3.62, C = 4 3.03 -> 3.32 (tools/d_kernel_probe.py, 19 molecules per call)
     if (whole_rows && p.ct < 32 && nsz > 8 && nsz % 8 == 4 && p.nw == 8) p.nw = 4;
+    // One or four channels per workgroup (forward_single, a few element types): the multi-sub-tile kernel (two or four sub-tiles
+    // per wave) needs an even number of waves per slab, and these launches store too little to care where a row is cut. Rows
+    // of 9 ... 15 sub-tiles in chunks of eight instead of whole (grids of whole 16-byte quads only; kernel ms whole / 4 / 8,
+    // cfg-2 density, tools/jobs/narrow_bigd_sweep.sh): C = 1 D = 88 0.155 / 0.097 / 0.108, 104 0.184 / 0.100 / 0.096, 112 0.124 /
+    // 0.098 / 0.094, 120 0.190 / 0.097 / 0.091; C = 4 D = 88 0.186 / 0.126 / 0.124, 104 0.200 / 0.168 / 0.115, 112 0.147 / 0.125 /
+    // 0.114, 120 0.213 / 0.170 / 0.110 (whole calls 0.27 -> 0.19 ms at D = 120). Nine sub-tiles (D = 72) take chunks of four (0.141
+    // / 0.107 / 0.120 and 0.164 / 0.130 / 0.137); ten (D = 80) stay whole - five waves of two sub-tiles, 0.111 / 0.099 / 0.114 with
+    // the smaller pre-pass of the whole row. Eight channels keep whole rows (D = 88 0.228 / 0.309 / 0.254).
+    if (whole_rows && quad_rows && p.ct <= 4 && nsz > 8 && nsz < 16 && p.nw == nsz && nsz != 10) p.nw = nsz == 9 ? 4 : 8;
     if (force_nw > 0 && force_nw <= 16) p.nw = std::min(force_nw, nsz); // "nw" measurement knob
     p.nzc = (nsz + p.nw - 1) / p.nw;
 }
@@ -93,7 +102,7 @@ mvx_plan plan_call(const mvx_plan_query &q, const PlanKnobs &k) {
         }
     }
     p.route = f64 ? (mx64 ? MVX_ROUTE_F64_MX : MVX_ROUTE_F64_DENSE) : (direct ? MVX_ROUTE_DIRECT : MVX_ROUTE_BINNED);
-    if (p.route == MVX_ROUTE_BINNED) plan_slabs(D, 8, true, k.force_nw, p);
+    if (p.route == MVX_ROUTE_BINNED) plan_slabs(D, 8, true, k.force_nw, p, !f64 && D % 4 == 0 && q.out_aligned16 != 0);
     const long long per_mol = (long long)p.nsx * p.nsy * p.nzc;
 
     // ---- remainder channels --------------------------------------------------------------------------------------------

@@ -349,6 +349,35 @@ def test_medium_density_multi_round_slab_lines(mv):
     assert_gaussian(outg, refg)  # sums of up to ~60 terms
 
 
+@pytest.mark.parametrize("D,C_,mode", [(72, 4, "types"), (88, 1, "single"), (88, 4, "types"), (100, 3, "features"), (104, 4, "features"),
+                                       (112, 1, "single"), (120, 4, "types"), (120, 2, "features")])
+def test_long_rows_in_chunks_for_one_and_four_channel_launches(mv, D, C_, mode):
+    """plan_slabs: launches of one or four channels per workgroup cut rows of 9 ... 15 sub-tiles into chunks of eight (four at
+    D = 72) so that the multi-sub-tile kernel applies - pieces that share 64-byte blocks with their neighbours. Against the
+    oracle, Gaussian and binary."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(7000 + 10 * D + C_)
+    n = int(4000 * (D / 64.0) ** 3)
+    W_ = 0.5 * (D - 1)
+    xyz = rng.uniform(-W_ / 2, W_ / 2, (n, 3))
+    for density in ("gaussian", "binary"):
+        v = mv.create_voxelizer(0.5, D, "scalar", density, "hip", output="numpy", sigma=0.6)
+        if mode == "single":
+            out = v.forward_single(xyz, None, 1.0)
+            ref = c_oracle.voxelize(xyz, None, 1.0, dimension=D, density=density, sigma=0.6)
+        elif mode == "types":
+            t = rng.integers(0, C_, n)
+            t[0] = C_ - 1
+            out = v.forward_types(xyz, None, t, 1.0)
+            ref = c_oracle.voxelize(xyz, t, 1.0, dimension=D, density=density, sigma=0.6, num_channels=C_)
+        else:
+            f = rng.random((n, C_)).astype(np.float32)
+            out = v.forward_features(xyz, None, f, 1.0)
+            ref = c_oracle.voxelize(xyz, f, 1.0, dimension=D, density=density, sigma=0.6)
+        _compare(out, ref, density == "binary" and mode != "features")
+
+
 @pytest.mark.parametrize("C_,mode", [(1, "single"), (4, "types"), (8, "features"), (16, "features"), (40, "features")])
 def test_rows_of_twelve_sub_tiles_in_chunks_of_four(mv, C_, mode):
     """D = 96: narrow launches cut the row into three chunks of four sub-tiles (plan_slabs), 32-channel chunks into 8 + 4;

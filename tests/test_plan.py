@@ -127,6 +127,19 @@ def test_rows_of_8k_plus_4_sub_tiles_take_chunks_of_four_in_narrow_launches():
     assert plan(100, 16, 8, 4000)["nw"] == 13  # (rows that are not multiples of 32 voxels stay whole)
 
 
+def test_long_rows_of_narrow_launches_are_cut_so_that_the_multi_sub_tile_kernel_applies():
+    """One or four channels per workgroup: rows of 9 ... 15 sub-tiles in chunks of eight (nine: four; ten stay whole) on grids of
+    whole 16-byte quads - C = 4 at D = 120: kernel 0.213 -> 0.110 ms; eight and more channels keep whole rows."""
+    for D, nw, nzc in ((72, 4, 3), (80, 10, 1), (88, 8, 2), (100, 8, 2), (104, 8, 2), (112, 8, 2), (120, 8, 2), (128, 8, 2)):
+        for C_ in (1, 3, 4):
+            p = plan(D, C_, 8, 4000)
+            assert (p["nw"], p["nzc"]) == (nw, nzc), (D, C_, p)
+    for D, nw in ((72, 9), (88, 11), (104, 13), (120, 15)):
+        assert plan(D, 8, 8, 4000)["nw"] == nw and plan(D, 16, 8, 4000)["nw"] == nw and plan(D, 32, 8, 4000)["nw"] == nw
+    assert plan(66, 4, 8, 4000)["nw"] == 9  # (rows that are not whole quads: run-wise write-out, whole rows)
+    assert plan(88, 4, 8, 4000, out_aligned16=False)["nw"] == 11
+
+
 def test_pacing_thresholds():
     """mvx_tuning.h: rounds paced from 49 152 workgroups (96 cfg-2 molecules: 64 molecules gain 2 % in a sustained loop and lose
     5 % in short bursts, 128 gain 3 %), empty slabs held back beyond 4 096."""
