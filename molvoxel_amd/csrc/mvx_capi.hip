@@ -547,7 +547,7 @@ int run(mvx_handle *h, const RunArgs &r) {
     const bool lr_blocks = plan.lane_range != 0;
     const bool runs = !f64 && !va.p.vec_store;
     const bool lane_range = lr_blocks || runs;
-    auto lane_range_for = [&](int32_t ct_) { return lr_blocks || (runs && ct_ != 32); };
+    auto lane_range_for = [&](int32_t) { return lr_blocks; }; // (run-wise write-out: voxelize_runs_kernel / voxelize_pair_runs_kernel)
 
     if (direct) {
         DirectArgs da;

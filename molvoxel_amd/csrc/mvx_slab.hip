@@ -263,6 +263,20 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : BIG_WAVES_PER_SIMD))
 #include "mvx_slab_body.inc"
 }
 
+// Narrow chunks (1 ... 16 channels) of such grids: the candidate-pair walk (OpsPair) with the run-wise write-out. Until late in
+// round 4 these launches went to the per-lane-range kernels (OpsF32: one candidate and one voxel per lane step, six index
+// comparisons per voxel), the only narrow ones that carried store_runs: D = 49 / 50 / 63 ran at half the rate of D = 48 / 64
+// (C = 4, kernel ms: 0.238 / 0.228 / 0.200 against 0.120 / 0.099 - profiles/r04_slab_plans.txt).
+template <int CT, bool GAUSS, int MAXT>
+__global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 8 : BIG_WAVES_PER_SIMD))
+    voxelize_pair_runs_kernel(const unsigned *__restrict__ rec, const unsigned *__restrict__ w, const uint2 *__restrict__ slist,
+                              const uint2 *__restrict__ slist_ext, const double *__restrict__ Tc, const float *__restrict__ kc,
+                              float *__restrict__ out, const VoxParams P) {
+    typedef OpsPair<CT, GAUSS, true> Ops;
+    constexpr bool GROUPED = false;
+#include "mvx_slab_body.inc"
+}
+
 // (Measured and removed, round 3: channel counts of 32 k + r with the remainder chunk's workgroups - CTR vector-ALU
 // accumulators - in the SAME launch as the full chunks' (a kernel that branches on the chunk index into two inclusions of
 // the slab body). Bit-identical, and slower than the second launch it replaced: C = 33 0.618 against 0.580 ms per 64
@@ -372,8 +386,10 @@ struct LaunchFn {
                 static LdsLimit raised_runs;
                 kern = &voxelize_runs_kernel<GAUSS, MAXT>;
                 state = &raised_runs;
-            } else if (!LANE_RANGE) {
-                return hipErrorInvalidConfiguration; // (only the per-lane-range kernels carry store_runs)
+            } else if constexpr (!LANE_RANGE) { // narrow chunks: the pair walk with store_runs
+                static LdsLimit raised_pair_runs;
+                kern = &voxelize_pair_runs_kernel<CT, GAUSS, MAXT>;
+                state = &raised_pair_runs;
             }
         }
         hipError_t e = raise_lds_limit(kern, lds, *state);
