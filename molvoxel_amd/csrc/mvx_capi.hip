@@ -543,7 +543,8 @@ int run(mvx_handle *h, const RunArgs &r) {
     va.p.dbg = h->dbg;
 #endif
     // float32 grids whose rows are not whole 16-byte quads need the run-wise write-out (store_runs): compiled into the
-    // per-lane-range kernels and into voxelize_runs_kernel (the matrix-core walk of 32-channel chunks), nowhere else
+    // per-lane-range kernels, voxelize_runs_kernel (the matrix-core walk of 32-channel chunks) and voxelize_pair_runs_kernel
+    // (the candidate-pair walk of narrow chunks), nowhere else
     const bool lr_blocks = plan.lane_range != 0;
     const bool runs = !f64 && !va.p.vec_store;
     const bool lane_range = lr_blocks || runs;

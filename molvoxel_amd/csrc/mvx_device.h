@@ -627,8 +627,9 @@ __device__ __forceinline__ void store_runs(const float *tile, const RunLayout &R
 
 // Write-out of one slab. `any` false: zero fill without the LDS round trip. Begins with a barrier (the union region
 // may still hold candidate rows) and ends without one.
-// RUNS: the kernel also serves grids whose rows are not whole 16-byte quads (store_runs). Only the per-lane-range kernels
-// are compiled with it (the host sends such grids there): the aligned-grid kernels keep their register budget.
+// RUNS: the kernel also serves grids whose rows are not whole 16-byte quads (store_runs). Compiled into the per-lane-range
+// kernels and the run-wise kernels (voxelize_runs_kernel, voxelize_pair_runs_kernel) only: the aligned-grid kernels keep their
+// register budget.
 template <int CT, bool RUNS, int CRMAX = CR_F32>
 __device__ __forceinline__ void write_slab(const float2v (&acc)[(CT + 1) / 2], bool any, float *tile, int tid, int lane,
                                            int wave, int NW, int b, int cbase, int x0, int y0, int z0, float *out,

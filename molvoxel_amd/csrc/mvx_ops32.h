@@ -231,7 +231,7 @@ struct OpsMx32 {
 template <int CT_, bool GAUSS, bool RUNS_ = false>
 struct OpsPair {
     static constexpr int CT = CT_;
-    static constexpr bool RUNS = RUNS_; // carries the run-wise write-out (store_runs): the per-molecule kernel only
+    static constexpr bool RUNS = RUNS_; // carries the run-wise write-out (store_runs): the per-molecule kernel and voxelize_pair_runs_kernel
     static constexpr bool GROUPED = false;
     static constexpr bool VSTAGE = true;
     static constexpr bool PRESTAGE = false;
