@@ -55,6 +55,9 @@ void plan_slabs(int D, int max_waves, bool whole_rows, int force_nw, mvx_plan &p
     // / 0.107 / 0.120 and 0.164 / 0.130 / 0.137); ten (D = 80) stay whole - five waves of two sub-tiles, 0.111 / 0.099 / 0.114 with
     // the smaller pre-pass of the whole row. Eight channels keep whole rows (D = 88 0.228 / 0.309 / 0.254).
     if (whole_rows && quad_rows && p.ct <= 4 && nsz > 8 && nsz < 16 && p.nw == nsz && nsz != 10) p.nw = nsz == 9 ? 4 : 8;
+    // ... and forward_single (one channel) on rows of five or seven sub-tiles (D = 40, 56): chunks of four - kernel 0.128 -> 0.116 and
+    // 0.126 -> 0.099 ms, calls 0.162 -> 0.156 and 0.157 -> 0.141 (four channels: no gain; three sub-tiles, D = 24: whole rows win)
+    if (whole_rows && quad_rows && p.ct == 1 && (nsz == 5 || nsz == 7) && p.nw == nsz) p.nw = 4;
     if (force_nw > 0 && force_nw <= 16) p.nw = std::min(force_nw, nsz); // "nw" measurement knob
     p.nzc = (nsz + p.nw - 1) / p.nw;
 }

@@ -350,11 +350,11 @@ def test_medium_density_multi_round_slab_lines(mv):
 
 
 @pytest.mark.parametrize("D,C_,mode", [(72, 4, "types"), (88, 1, "single"), (88, 4, "types"), (100, 3, "features"), (104, 4, "features"),
-                                       (112, 1, "single"), (120, 4, "types"), (120, 2, "features")])
+                                       (112, 1, "single"), (120, 4, "types"), (120, 2, "features"), (40, 1, "single"), (56, 1, "single")])
 def test_long_rows_in_chunks_for_one_and_four_channel_launches(mv, D, C_, mode):
     """plan_slabs: launches of one or four channels per workgroup cut rows of 9 ... 15 sub-tiles into chunks of eight (four at
-    D = 72) so that the multi-sub-tile kernel applies - pieces that share 64-byte blocks with their neighbours. Against the
-    oracle, Gaussian and binary."""
+    D = 72) so that the multi-sub-tile kernel applies - pieces that share 64-byte blocks with their neighbours; forward_single
+    cuts rows of five / seven sub-tiles (D = 40, 56) into chunks of four. Against the oracle, Gaussian and binary."""
     from oracle import c_oracle
 
     rng = np.random.default_rng(7000 + 10 * D + C_)

@@ -136,6 +136,9 @@ def test_long_rows_of_narrow_launches_are_cut_so_that_the_multi_sub_tile_kernel_
             assert (p["nw"], p["nzc"]) == (nw, nzc), (D, C_, p)
     for D, nw in ((72, 9), (88, 11), (104, 13), (120, 15)):
         assert plan(D, 8, 8, 4000)["nw"] == nw and plan(D, 16, 8, 4000)["nw"] == nw and plan(D, 32, 8, 4000)["nw"] == nw
+    # forward_single on rows of five / seven sub-tiles: chunks of four (kernel 0.126 -> 0.099 ms at D = 56); four channels keep whole rows
+    for D, nw1, nw4 in ((40, 4, 5), (56, 4, 7), (24, 3, 3), (48, 6, 6)):
+        assert plan(D, 1, 8, 1000, mode="single")["nw"] == nw1 and plan(D, 4, 8, 1000)["nw"] == nw4, D
     assert plan(66, 4, 8, 4000)["nw"] == 9  # (rows that are not whole quads: run-wise write-out, whole rows)
     assert plan(88, 4, 8, 4000, out_aligned16=False)["nw"] == 11
 
